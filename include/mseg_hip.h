@@ -1,0 +1,183 @@
+/*
+ * mseg_hip.h — C ABI of libmseg_hip.so, the gfx950 (MI355X / CDNA4) kernel library under the
+ * microbeSEG U-Net train / infer / watershed hot path.
+ *
+ * The reference (hip-satomi/microbeSEG) is pure Python on stock torch.nn / scipy / scikit-image and defines
+ * no FFI of its own.  Each entry point below therefore cites the reference *call site* whose
+ * library op it replaces.  All pointers are DEVICE pointers unless a name ends in `_host`; the library never
+ * allocates user-visible memory, never synchronises the stream on the compute path, and returns 0 on success
+ * or a negative MSEG_E* code (never throws across the boundary).  `stream` is a hipStream_t passed as void*.
+ *
+ * Activation tensors are NHWC fp32 ("pixel-major"): element (n, y, x, c) at ((n*H + y)*W + x)*C + c.
+ * A network input/output with one channel is bit-identical in NCHW and NHWC, which is how the Python boundary
+ * (NCHW, src/utils/unets.py:349,463) maps onto this layout without a copy.
+ */
+#ifndef MSEG_HIP_H
+#define MSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSEG_OK 0
+#define MSEG_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MSEG_ELAUNCH (-2)  /* hipLaunch / runtime error (mseg_last_hip_error() has the hipError_t) */
+#define MSEG_EWORKSPACE (-3)
+
+/* activation ids — reference: src/utils/unets.py:115-124 (relu / leakyrelu / elu / mish), Mish at :81-89 */
+#define MSEG_ACT_NONE 0
+#define MSEG_ACT_RELU 1
+#define MSEG_ACT_LEAKY 2 /* negative_slope 0.01 (torch default) */
+#define MSEG_ACT_ELU 3   /* alpha 1.0 */
+#define MSEG_ACT_MISH 4  /* x * tanh(softplus(x)), softplus threshold 20 */
+
+/* normalisation ids — reference: src/utils/unets.py:127-134 */
+#define MSEG_NORM_BN 0 /* BatchNorm2d, stats over (N,H,W) */
+#define MSEG_NORM_GN 1 /* GroupNorm(8, C), stats over (C/8,H,W) per sample */
+#define MSEG_NORM_IN 2 /* InstanceNorm2d, stats over (H,W) per (sample, channel), no affine */
+
+/* A tensor operand that is *normalised on load*: value(n,p,c) = act(ptr[...]) * scale[n*ss + c] + shift[n*ss + c].
+ * scale == NULL means "no affine" (identity), act == MSEG_ACT_NONE means no activation.
+ * This is how conv -> activation -> norm (src/utils/unets.py:163-173: ConvBlock.forward) is executed without ever
+ * materialising the normalised tensor: the producing conv stores z = conv(x)+b, the consumer applies act+norm. */
+typedef struct MsegSrc {
+  const float* ptr;   /* [N][H][W][C] */
+  const float* scale; /* [N][C] (ss == C) or [C] (ss == 0), or NULL */
+  const float* shift;
+  int32_t C;
+  int32_t act;
+  int32_t ss;
+  int32_t reserved;
+} MsegSrc;
+
+/* ---- implicit-GEMM convolution family (fp32 MFMA v_mfma_f32_32x32x2_f32) ---------------------------------
+ * Replaces nn.Conv2d 3x3 s1/s2 (unets.py:112,137,192), nn.ConvTranspose2d 2x2 s2 (unets.py:244) and the
+ * data-gradients of both (autograd of the same modules, train.py:488).
+ *   out[m][n] = bias[n] + sum_t sum_c  A_t[m][c] * w[t][n][c]
+ * m indexes the "M-space" pixels (NB, Ho, Wo); A_t[m] is the source pixel selected by tap t:
+ *   mode CONV : (iy, ix) = (oy*stride + ky - pad, ox*stride + kx - pad)
+ *   mode TCONV: ty = oy + pad - ky must be divisible by stride, iy = ty / stride   (transposed conv = dgrad)
+ * the source is the channel-concatenation of src[0..nsrc) (torch.cat([up, skip], 1): unets.py:373,492,502).
+ * Epilogue PLAIN: dst = (n < split ? dst0[m*ld0 + n] : dst1[m*ld1 + n - split]) (+= if accN)   (split >= Ngemm: single dst)
+ * Epilogue SCATTER2X2 (ConvTranspose2d as a 1x1 GEMM with N = 4*Cq): n = (a*2+b)*Cq + co,
+ *   dst0[((img*2Ho + 2oy+a)*2Wo + 2ox+b)*Cq + co], bias index co.                                          */
+#define MSEG_MODE_CONV 0
+#define MSEG_MODE_TCONV 1
+#define MSEG_EPI_PLAIN 0
+#define MSEG_EPI_SCATTER2X2 1
+#define MSEG_MORDER_LINEAR 0
+#define MSEG_MORDER_PARITY 1 /* M ordered by (oy&1, ox&1) class first: lets stride-2 TCONV tiles skip dead taps */
+
+typedef struct MsegIgemm {
+  MsegSrc src[2];
+  const float* w;    /* packed [T][Ngemm][Kpad], Kpad % 4 == 0, zero padded beyond Cin */
+  const float* bias; /* [Ngemm] (PLAIN) / [Cq] (SCATTER2X2) or NULL */
+  float* dst0;
+  float* dst1;
+  int32_t nsrc, Cin, Kpad;
+  int32_t NB, Hi, Wi, Ho, Wo;
+  int32_t KH, KW, stride, pad, mode, morder;
+  int32_t Ngemm, epi, split, ld0, ld1, acc0, acc1, Cq;
+} MsegIgemm;
+
+int mseg_igemm(const MsegIgemm* p, void* stream);
+
+/* weight gradient: G[t][mch][nch] = sum_p P[p][mch] * Q[gather(p, t)][nch], written to dst[(mch*Nch + nch)*T + t]
+ * which *is* torch's layout for both Conv2d.weight (Cout,Cin,KH,KW) [P = dz, Q = conv input] and
+ * ConvTranspose2d.weight (Cin,Cout,2,2) [P = convT input, Q = d(convT output), KH=KW=2, stride 2, pad 0].
+ * gather: (qy, qx) = (py*stride + ky - pad, px*stride + kx - pad).  Split-K over pixels into `ws`, then a
+ * fixed-order reduction (deterministic).  Nch_store <= Nch lets a zero-padded Q (first layer, Cin=1->4) drop pads. */
+typedef struct MsegWgrad {
+  MsegSrc P;
+  MsegSrc Q[2];
+  float* ws;  /* >= mseg_wgrad_workspace_bytes() */
+  float* dst; /* [Mch][Nch_store][T] */
+  int32_t nq, Nch, Nch_store;
+  int32_t NB, Hp, Wp, Hq, Wq;
+  int32_t KH, KW, stride, pad;
+  int32_t splits; /* 0 = choose */
+  int32_t reserved;
+} MsegWgrad;
+
+size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);
+int mseg_wgrad(const MsegWgrad* p, void* stream);
+
+/* strided repack of a weight tensor into the [T][R][Cpad] GEMM operand:
+ *   dst[(t*R + r)*Cpad + c] = c < C ? src[t*st + r*sr + c*sc] : 0                                          */
+int mseg_pack_weight(const float* src, float* dst, int T, int R, int C, int Cpad, int st, int sr, int sc, void* stream);
+
+/* ---- normalisation (BatchNorm2d / GroupNorm(8) / InstanceNorm2d applied AFTER the activation) --------------
+ * forward statistics of a = act(z) over an NHWC tensor, fp64 accumulation:
+ *   mseg_norm_stats: fills scale/shift ([N][C], ss = C for GN/IN; [C], ss = 0 for BN) such that
+ *   y = a*scale + shift, and mean/rstd ([C] BN, [N][8] GN, [N][C] IN) for the backward.
+ *   BN training additionally updates running_mean/var with `momentum` (unbiased var), torch semantics
+ *   (unets.py:127-128; torch BatchNorm2d defaults eps 1e-5, momentum 0.1).
+ * ws: fp64 scratch, mseg_norm_workspace_bytes(N, HW, C).                                                      */
+size_t mseg_norm_workspace_bytes(int N, int HW, int C);
+int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
+                    const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum, void* ws, void* stream);
+/* eval-mode BatchNorm: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale */
+int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* backward through y = norm(act(z)): given gy = dL/dy writes dz = dL/dz (may alias gy), dgamma, dbeta
+ * (NULL for IN) and optionally dbias_prev[c] = sum_p dz (the producing conv's bias gradient).               */
+int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
+                  const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, float* dbias,
+                  void* ws, void* stream);
+
+/* ---- 1x1 output heads (unets.py:347,460-461) ------------------------------------------------------------
+ * out (NCHW, [N][Co][HW]) = W[Co][C] . norm-on-load(src) + b ; Co <= 4.                                      */
+int mseg_head_fwd(const MsegSrc* src, int N, int HW, const float* w, const float* b, int Co, float* out_nchw,
+                  void* stream);
+/* gy[N][HW][C] = sum_co gout[n][co][p] * W[co][c];  dW[Co][C], db[Co] (fp64 accumulation, deterministic) */
+size_t mseg_head_bwd_workspace_bytes(int N, int HW, int C, int Co);
+int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw, float* gy,
+                  float* dW, float* db, void* ws, void* stream);
+
+/* ---- losses (src/training/losses.py) -----------------------------------------------------------------------
+ * smooth-L1 (beta 1, mean) / L1 / MSE of one head, forward value and gradient in one pass (losses.py:24-32).
+ * kind: 0 smooth_l1, 1 l1, 2 l2.  loss_out[0] = mean loss; grad = d(loss)/d(pred) * gscale_dev[0] (or 1).    */
+size_t mseg_loss_workspace_bytes(size_t n);
+int mseg_regression_loss(const float* pred, const float* target, size_t n, int kind, float* loss_out,
+                         void* ws, void* stream);
+int mseg_regression_loss_bwd(const float* pred, const float* target, size_t n, int kind, const float* gscale_dev,
+                             float* grad, void* stream);
+/* ce_dice (losses.py:71-97): CE(logits, y) + 0.5 * sum_{c=1,2} c * (1 - (2 sum g p + 1)/(sum g^2 + sum p^2 + 1)),
+ * logits NCHW [N][3][HW], labels int64 [N][HW].  sums[6] = {sum g1 p1, sum p1^2, sum g1, sum g2 p2, sum p2^2, sum g2}
+ * are exposed so a data-parallel caller can all-reduce them between the two calls.        */
+int mseg_ce_dice_fwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice, double* sums6,
+                     double* ce_sum, void* ws, void* stream);
+int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice, const double* sums6,
+                     double total_px, const float* gscale_dev, float* grad, void* stream);
+
+/* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
+int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
+                           float beta1, float beta2, float eps, int step, void* stream);
+
+/* ---- inference post-processing (src/inference/postprocessing.py) --------------------------------------------
+ * distance_postprocessing(border, cell, th_seed, th_cell) (postprocessing.py:7-59) and
+ * boundary_postprocessing(softmax probs HWC) (postprocessing.py:62-90): gaussian(0.5) -> thresholds -> 8-conn CCL
+ * -> small-seed removal -> relabel -> marker watershed (4-conn), labels bit-exact.  Inputs: device fp32 [H][W]
+ * (distance) / [H][W][3] (boundary); output: device uint16 [H][W].  `col_major_ids` selects the id numbering the
+ * reference gets for (H,W,1) inputs.  status_dev[0] receives flags (bit0: exact
+ * serial path was used).                                                                                        */
+size_t mseg_postproc_workspace_bytes(int H, int W);
+int mseg_distance_postprocess(const float* border, const float* cell, int H, int W, float th_cell, float th_seed,
+                              int col_major_ids, uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev,
+                              void* ws, size_t ws_bytes, void* stream);
+int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, uint16_t* labels, int32_t* n_instances_dev,
+                              int32_t* status_dev, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------------------------- */
+int mseg_version(void);
+const char* mseg_strerror(int code);
+int mseg_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSEG_HIP_H */

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds libmseg_hip.so for gfx950 in-tree (the .so travels to the GPU box with the snapshot).
+set -e
+cd "$(dirname "$0")"
+OUT=../libmseg_hip.so
+SRCS="igemm.hip wgrad.hip norm.hip head.hip loss.hip api_misc.hip"
+[ -f postproc.hip ] && SRCS="$SRCS postproc.hip"
+mkdir -p ../_build
+OBJS=""
+pids=()
+for s in $SRCS; do
+  o=../_build/${s%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
+echo "built $OUT"

@@ -1,0 +1,87 @@
+// common.h — shared device helpers for libmseg_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mseg_hip.h"
+
+extern "C" void mseg_set_hip_error(int e);
+
+#define MSEG_LAUNCH_CHECK()                           \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) {                          \
+      mseg_set_hip_error((int)e__);                   \
+      return MSEG_ELAUNCH;                            \
+    }                                                 \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- activations (reference: src/utils/unets.py:81-89,115-124) -------------------------------------------
+__device__ __forceinline__ float mseg_softplus(float x) {
+  // torch.nn.functional.softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float x) {
+  if (ACT == MSEG_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (ACT == MSEG_ACT_LEAKY) return x > 0.f ? x : 0.01f * x;
+  if (ACT == MSEG_ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (ACT == MSEG_ACT_MISH) return x * tanhf(mseg_softplus(x));
+  return x;
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case MSEG_ACT_RELU: return act_fwd_t<MSEG_ACT_RELU>(x);
+    case MSEG_ACT_LEAKY: return act_fwd_t<MSEG_ACT_LEAKY>(x);
+    case MSEG_ACT_ELU: return act_fwd_t<MSEG_ACT_ELU>(x);
+    case MSEG_ACT_MISH: return act_fwd_t<MSEG_ACT_MISH>(x);
+    default: return x;
+  }
+}
+
+// d act(z) / dz, following torch autograd of the reference modules
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  switch (act) {
+    case MSEG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case MSEG_ACT_LEAKY: return z > 0.f ? 1.f : 0.01f;
+    case MSEG_ACT_ELU: return z > 0.f ? 1.f : expf(z);  // alpha * exp(z)
+    case MSEG_ACT_MISH: {
+      float sp = mseg_softplus(z);
+      float t = tanhf(sp);
+      float dsp = z > 20.f ? 1.f : 1.f / (1.f + expf(-z));  // softplus' = sigmoid below the threshold
+      return t + z * (1.f - t * t) * dsp;
+    }
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float4 act_fwd4(float4 v, int act) {
+  if (act == MSEG_ACT_NONE) return v;
+  if (act == MSEG_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+  }
+  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
+  return v;
+}
+
+// norm-on-load of 4 consecutive channels c..c+3 of sample n from an MsegSrc
+__device__ __forceinline__ float4 src_transform4(float4 v, const MsegSrc& s, int n, int c) {
+  v = act_fwd4(v, s.act);
+  if (s.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(s.scale + (size_t)n * s.ss + c);
+    const float4 sh = *reinterpret_cast<const float4*>(s.shift + (size_t)n * s.ss + c);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

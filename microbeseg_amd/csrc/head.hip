@@ -1,0 +1,202 @@
+// head.hip — the 1x1 output convolutions (src/utils/unets.py:347 UNet head, :460-461 DUNet heads).
+// HBM-bound: one read of the last decoder tensor (normalised on load), Co <= 4 dot products per pixel.
+// Output / incoming gradient are NCHW ([N][Co][HW]) because that is the layout of the Python boundary.
+#include "common.h"
+
+#define HEAD_MAXCO 4
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const MsegSrc s, int N, int HW, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int Co, int lpp,
+                                                       float* __restrict__ out) {
+  const int C4 = s.C >> 2;
+  const long long total = (long long)N * HW;
+  const int sub = threadIdx.x % lpp;
+  const long long ppb = blockDim.x / lpp;  // pixels per block iteration
+  for (long long base = (long long)blockIdx.x * ppb; base < total; base += (long long)gridDim.x * ppb) {
+    // all lanes of a wave stay in the loop together (shuffles below); out-of-range pixels contribute 0
+    const long long pix = base + threadIdx.x / lpp;
+    const bool valid = pix < total;
+    const int n = valid ? (int)(pix / HW) : 0;
+    float acc[HEAD_MAXCO] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      for (int c4 = sub; c4 < C4; c4 += lpp) {
+        float4 v = *reinterpret_cast<const float4*>(s.ptr + (size_t)pix * s.C + c4 * 4);
+        v = src_transform4(v, s, n, c4 * 4);
+#pragma unroll
+        for (int co = 0; co < HEAD_MAXCO; ++co) {
+          if (co < Co) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)co * s.C + c4 * 4);
+            acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+          }
+        }
+      }
+    }
+    for (int o = lpp >> 1; o > 0; o >>= 1) {
+#pragma unroll
+      for (int co = 0; co < HEAD_MAXCO; ++co) acc[co] += __shfl_xor(acc[co], o, 64);
+    }
+    if (valid && sub == 0) {
+      const int p = (int)(pix - (long long)n * HW);
+      for (int co = 0; co < Co; ++co) out[((size_t)n * Co + co) * HW + p] = acc[co] + (b ? b[co] : 0.f);
+    }
+  }
+}
+
+static int head_lpp(int C4) {
+  int l = 1;
+  while (l * 2 <= C4 && l * 2 <= 16) l *= 2;
+  return l;
+}
+
+extern "C" int mseg_head_fwd(const MsegSrc* src, int N, int HW, const float* w, const float* b, int Co,
+                             float* out_nchw, void* stream) {
+  if (!src || !src->ptr || !w || !out_nchw || N <= 0 || HW <= 0 || Co <= 0 || Co > HEAD_MAXCO) return MSEG_EINVAL;
+  if (src->C <= 0 || (src->C & 3)) return MSEG_EINVAL;
+  const int lpp = head_lpp(src->C >> 2);
+  const long long total = (long long)N * HW;
+  const long long ppb = 256 / lpp;
+  long long blocks = (total + ppb - 1) / ppb;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *src, N, HW, w, b, Co,
+                     lpp, out_nchw);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------
+struct HeadGeom {
+  int N, HW, C, Co, chunks, rows_per_chunk;
+};
+
+static HeadGeom head_geom(int N, int HW, int C, int Co) {
+  HeadGeom g;
+  g.N = N; g.HW = HW; g.C = C; g.Co = Co;
+  int maxc = 1024 / (N > 0 ? N : 1);
+  if (maxc < 1) maxc = 1;
+  int chunks = HW / 512;
+  if (chunks > maxc) chunks = maxc;
+  if (chunks < 1) chunks = 1;
+  g.rows_per_chunk = (HW + chunks - 1) / chunks;
+  g.chunks = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
+  return g;
+}
+
+extern "C" size_t mseg_head_bwd_workspace_bytes(int N, int HW, int C, int Co) {
+  if (N <= 0 || HW <= 0 || C <= 0 || Co <= 0 || Co > HEAD_MAXCO) return 0;
+  HeadGeom g = head_geom(N, HW, C, Co);
+  return (size_t)N * g.chunks * (HEAD_MAXCO * (C + 1)) * sizeof(double);
+}
+
+// thread owns 4 channels, walks the pixels of its chunk: gy = sum_co g[co]*W[co][c..c+3]; dW partial sums fp64
+__global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom g, const float* __restrict__ w,
+                                                       const float* __restrict__ gout, float* __restrict__ gy,
+                                                       double* __restrict__ part) {
+  __shared__ double red[256 * 4 * HEAD_MAXCO];
+  __shared__ double redb[256];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int C4 = g.C >> 2;
+  const int CW = C4 < 256 ? C4 : 256;
+  const int rpi = 256 / CW;
+  const int cq = tid % CW, r0 = tid / CW;
+  const int row_begin = chunk * g.rows_per_chunk;
+  int row_end = row_begin + g.rows_per_chunk;
+  if (row_end > g.HW) row_end = g.HW;
+  double* pout = part + ((size_t)n * g.chunks + chunk) * (HEAD_MAXCO * (g.C + 1));
+
+  for (int cbase = 0; cbase < C4; cbase += CW) {
+    const int c4 = cbase + cq;
+    const bool active = (c4 < C4) && (r0 < rpi);
+    double dw[HEAD_MAXCO][4];
+    double dbs[HEAD_MAXCO];
+#pragma unroll
+    for (int co = 0; co < HEAD_MAXCO; ++co) {
+      dbs[co] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[co][j] = 0.0;
+    }
+    if (active) {
+      const int c = c4 * 4;
+      float4 wv[HEAD_MAXCO];
+#pragma unroll
+      for (int co = 0; co < HEAD_MAXCO; ++co)
+        wv[co] = co < g.Co ? *reinterpret_cast<const float4*>(w + (size_t)co * g.C + c) : make_float4(0, 0, 0, 0);
+      for (int r = row_begin + r0; r < row_end; r += rpi) {
+        const size_t off = ((size_t)n * g.HW + r) * g.C + c;
+        float4 yv = *reinterpret_cast<const float4*>(s.ptr + off);
+        yv = src_transform4(yv, s, n, c);
+        float4 o = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int co = 0; co < HEAD_MAXCO; ++co) {
+          if (co < g.Co) {
+            const float gv = gout[((size_t)n * g.Co + co) * g.HW + r];
+            o.x += gv * wv[co].x; o.y += gv * wv[co].y; o.z += gv * wv[co].z; o.w += gv * wv[co].w;
+            dw[co][0] += (double)gv * yv.x; dw[co][1] += (double)gv * yv.y;
+            dw[co][2] += (double)gv * yv.z; dw[co][3] += (double)gv * yv.w;
+            if (c4 == 0) dbs[co] += gv;
+          }
+        }
+        *reinterpret_cast<float4*>(gy + off) = o;
+      }
+    }
+    for (int co = 0; co < g.Co; ++co) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(tid * HEAD_MAXCO + co) * 4 + j] = dw[co][j];
+    }
+    __syncthreads();
+    if (r0 == 0 && c4 < C4) {
+      for (int co = 0; co < g.Co; ++co) {
+        double t[4] = {0, 0, 0, 0};
+        for (int k = 0; k < rpi; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] += red[((k * CW + cq) * HEAD_MAXCO + co) * 4 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pout[(size_t)co * g.C + c4 * 4 + j] = t[j];
+      }
+    }
+    __syncthreads();
+    if (cbase == 0) {
+      // bias gradient: threads with c4 == 0 (cq == 0) hold the per-row-slice sums
+      for (int co = 0; co < g.Co; ++co) {
+        redb[tid] = (cq == 0 && r0 < rpi) ? dbs[co] : 0.0;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int k = 0; k < rpi; ++k) t += redb[k * CW];
+          pout[(size_t)HEAD_MAXCO * g.C + co] = t;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ void head_bwd_reduce_kernel(const double* __restrict__ part, HeadGeom g, float* __restrict__ dW,
+                                       float* __restrict__ db) {
+  const int per = HEAD_MAXCO * (g.C + 1);
+  const int blocks = g.N * g.chunks;
+  const int total = g.Co * g.C + g.Co;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int slot;
+    if (i < g.Co * g.C) slot = i;  // [co][c]
+    else slot = HEAD_MAXCO * g.C + (i - g.Co * g.C);
+    double s = 0.0;
+    for (int k = 0; k < blocks; ++k) s += part[(size_t)k * per + slot];
+    if (i < g.Co * g.C) dW[i] = (float)s;
+    else if (db) db[i - g.Co * g.C] = (float)s;
+  }
+}
+
+extern "C" int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw,
+                             float* gy, float* dW, float* db, void* ws, void* stream) {
+  if (!src || !src->ptr || !w || !gout_nchw || !gy || !dW || !ws) return MSEG_EINVAL;
+  if (N <= 0 || HW <= 0 || Co <= 0 || Co > HEAD_MAXCO || src->C <= 0 || (src->C & 3)) return MSEG_EINVAL;
+  HeadGeom g = head_geom(N, HW, src->C, Co);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, *src, g, w, gout_nchw, gy, (double*)ws);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((Co * (src->C + 1) + 255) / 256), dim3(256), 0, st,
+                     (const double*)ws, g, dW, db);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -1,0 +1,333 @@
+// igemm.hip — gather implicit-GEMM convolution on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD — MI355X has no xf32/TF32 path).
+//
+// One kernel family covers (reference call sites in parentheses):
+//   * Conv2d 3x3 s1 p1 forward            (src/utils/unets.py:112,137)   mode CONV
+//   * Conv2d 3x3 s2 p1 forward (ConvPool) (src/utils/unets.py:192)       mode CONV, stride 2
+//   * data gradient of both               (autograd; train.py:488)       mode TCONV (+ parity M-order for s2)
+//   * ConvTranspose2d 2x2 s2 forward      (src/utils/unets.py:244)       1 tap, N = 4*Cout, SCATTER2X2 epilogue
+//   * its data gradient                                                  mode CONV, 2x2 taps, stride 2, pad 0
+//   * torch.cat([up, skip], 1)            (unets.py:373,492,502)         two sources, never materialised
+//   * activation + Batch/Group/InstanceNorm of the *producer* layer      applied while staging A (norm-on-load)
+//
+// Tiling: a workgroup (256 threads = 4 waves) owns BM output pixels x BN output channels; every K-step stages a
+// [BM][32] slab of gathered source pixels (one tap, 32 input channels) and a [BN][32] slab of weights in LDS
+// (row stride 36 floats -> conflict-free ds_read_b128), each wave accumulates a 64x64 block as 2x2 MFMA tiles.
+// The global loads of step s+1 are issued before the MFMAs of step s (register prefetch).
+#include "common.h"
+
+#define KC 32
+#define LDS_STRIDE 36
+
+template <int BM, int BN>
+struct IgemmCfg {
+  static constexpr int WM = (BN >= 128) ? 2 : 4;  // waves along M
+  static constexpr int WN = 4 / WM;               // waves along N
+  static constexpr int TM = BM / WM;              // per-wave rows   (multiple of 32)
+  static constexpr int TN = BN / WN;              // per-wave cols
+  static constexpr int MB = TM / 32;
+  static constexpr int NB = TN / 32;
+  static constexpr int AROWS = BM / 32;           // A rows staged per thread
+  static constexpr int BROWS = BN / 32;
+};
+
+struct RowInfo {
+  int n;    // image index, -1 = row beyond M
+  int oy, ox;
+};
+
+__device__ __forceinline__ RowInfo decode_row(const MsegIgemm& p, int m, int M) {
+  RowInfo r;
+  if (m >= M) { r.n = -1; r.oy = 0; r.ox = 0; return r; }
+  if (p.morder == MSEG_MORDER_PARITY) {
+    const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
+    const int per = p.NB * Hh * Wh;
+    const int cls = m / per;
+    int rem = m - cls * per;
+    r.n = rem / (Hh * Wh);
+    rem -= r.n * (Hh * Wh);
+    const int y2 = rem / Wh;
+    r.oy = 2 * y2 + (cls >> 1);
+    r.ox = 2 * (rem - y2 * Wh) + (cls & 1);
+  } else {
+    r.n = m / (p.Ho * p.Wo);
+    int rem = m - r.n * (p.Ho * p.Wo);
+    r.oy = rem / p.Wo;
+    r.ox = rem - r.oy * p.Wo;
+  }
+  return r;
+}
+
+// source pixel of (row, tap); returns false if the tap falls outside / on a dead phase
+__device__ __forceinline__ bool tap_coord(const MsegIgemm& p, const RowInfo& r, int ky, int kx, int& iy, int& ix) {
+  if (r.n < 0) return false;
+  if (p.mode == MSEG_MODE_CONV) {
+    iy = r.oy * p.stride + ky - p.pad;
+    ix = r.ox * p.stride + kx - p.pad;
+  } else {
+    const int ty = r.oy + p.pad - ky, tx = r.ox + p.pad - kx;
+    if (ty < 0 || tx < 0) return false;
+    if (p.stride == 2) {
+      if ((ty | tx) & 1) return false;
+      iy = ty >> 1; ix = tx >> 1;
+    } else {
+      iy = ty; ix = tx;
+    }
+  }
+  return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
+  using Cfg = IgemmCfg<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE + 4];
+  float* As = lds;
+  float* Bs = lds + BM * LDS_STRIDE;
+  unsigned* tapmask_s = reinterpret_cast<unsigned*>(lds + (BM + BN) * LDS_STRIDE);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+
+  const int M = p.NB * p.Ho * p.Wo;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  // consecutive workgroups share the A slab (same M tile, different N tile) -> L2 reuse
+  const int tile_m = blockIdx.x / ntiles_n;
+  const int tile_n = blockIdx.x - tile_m * ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int T = p.KH * p.KW;
+  const int srow = tid >> 3;  // staging row within a 32-row pass
+  const int scol = tid & 7;   // float4 column (4 channels)
+
+  RowInfo rows[Cfg::AROWS];
+#pragma unroll
+  for (int i = 0; i < Cfg::AROWS; ++i) rows[i] = decode_row(p, m0 + srow + 32 * i, M);
+
+  // which taps are live for at least one row of this tile
+  if (tid == 0) *tapmask_s = 0u;
+  __syncthreads();
+  {
+    unsigned mine = 0u;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < Cfg::AROWS; ++i) {
+        int iy, ix;
+        any |= tap_coord(p, rows[i], ky, kx, iy, ix);
+      }
+      if (any) mine |= (1u << t);
+    }
+    if (mine) atomicOr(tapmask_s, mine);
+  }
+  __syncthreads();
+  const unsigned tapmask = *tapmask_s;
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+
+  float4 ra[Cfg::AROWS];
+  float4 rb[Cfg::BROWS];
+
+  auto load_step = [&](int chunk, int t) {
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+    const int c = chunk * KC + scol * 4;
+    const bool cvalid = c < p.Cin;
+    const int si = (p.nsrc > 1 && c >= C0) ? 1 : 0;
+    const MsegSrc& s = p.src[si];
+    const int cl = si ? c - C0 : c;
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      int iy, ix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cvalid && tap_coord(p, rows[i], ky, kx, iy, ix)) {
+        const size_t pix = ((size_t)rows[i].n * p.Hi + iy) * p.Wi + ix;
+        v = *reinterpret_cast<const float4*>(s.ptr + pix * s.C + cl);
+        v = src_transform4(v, s, rows[i].n, cl);
+      }
+      ra[i] = v;
+    }
+    const float* wt = p.w + ((size_t)t * p.Ngemm) * p.Kpad;
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i) {
+      const int n = n0 + srow + 32 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.Ngemm && c < p.Kpad) v = *reinterpret_cast<const float4*>(wt + (size_t)n * p.Kpad + c);
+      rb[i] = v;
+    }
+  };
+
+  auto next_step = [&](int& chunk, int& t) -> bool {
+    for (;;) {
+      ++t;
+      if (t >= T) { t = 0; ++chunk; if (chunk >= nchunks) return false; }
+      if (tapmask & (1u << t)) return true;
+    }
+  };
+
+  int chunk = 0, t = -1;
+  bool have = (tapmask != 0u) && next_step(chunk, t);
+  if (have) load_step(chunk, t);
+
+  while (have) {
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i)
+      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
+    __syncthreads();
+
+    have = next_step(chunk, t);
+    if (have) load_step(chunk, t);
+
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < KC / 8; ++kk) {
+      float4 af[Cfg::MB], bf[Cfg::NB];
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+        af[a] = *reinterpret_cast<const float4*>(As + (wm * Cfg::TM + a * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+      for (int b = 0; b < Cfg::NB; ++b)
+        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn * Cfg::TN + b * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+        for (int b = 0; b < Cfg::NB; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ------------------------------------
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < Cfg::NB; ++b) {
+    const int n = n0 + wn * Cfg::TN + b * 32 + li;
+    const bool nvalid = n < p.Ngemm;
+    float bias = 0.f;
+    float* dst = p.dst0;
+    int ld = p.ld0, noff = n, accf = p.acc0;
+    int sa = 0, sb = 0;
+    if (p.epi == MSEG_EPI_SCATTER2X2) {
+      const int ab = nvalid ? n / p.Cq : 0;
+      const int co = n - ab * p.Cq;
+      sa = ab >> 1; sb = ab & 1;
+      noff = co;
+      if (p.bias && nvalid) bias = p.bias[co];
+    } else {
+      if (n >= p.split) { dst = p.dst1; ld = p.ld1; noff = n - p.split; accf = p.acc1; }
+      if (p.bias && nvalid) bias = p.bias[n];
+    }
+#pragma unroll
+    for (int a = 0; a < Cfg::MB; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * Cfg::TM + a * 32 + row;
+        if (!nvalid || m >= M) continue;
+        size_t off;
+        if (p.epi == MSEG_EPI_SCATTER2X2) {
+          const int img = m / (p.Ho * p.Wo);
+          const int rem = m - img * (p.Ho * p.Wo);
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          off = (((size_t)img * (2 * p.Ho) + 2 * oy + sa) * (2 * p.Wo) + 2 * ox + sb) * p.Cq + noff;
+        } else if (p.morder == MSEG_MORDER_PARITY) {
+          const RowInfo ri = decode_row(p, m, M);
+          off = (((size_t)ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * ld + noff;
+        } else {
+          off = (size_t)m * ld + noff;
+        }
+        float v = acc[a][b][r] + bias;
+        if (accf) v += dst[off];
+        dst[off] = v;
+      }
+    }
+  }
+}
+
+static int check_src(const MsegSrc& s) {
+  if (!s.ptr || s.C <= 0 || (s.C & 3)) return MSEG_EINVAL;
+  if ((s.scale == nullptr) != (s.shift == nullptr)) return MSEG_EINVAL;
+  if (s.scale && (s.ss & 3)) return MSEG_EINVAL;
+  return MSEG_OK;
+}
+
+extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
+  if (!pp) return MSEG_EINVAL;
+  const MsegIgemm& p = *pp;
+  if (p.nsrc < 1 || p.nsrc > 2) return MSEG_EINVAL;
+  int csum = 0;
+  for (int i = 0; i < p.nsrc; ++i) {
+    if (check_src(p.src[i])) return MSEG_EINVAL;
+    csum += p.src[i].C;
+  }
+  if (csum != p.Cin) return MSEG_EINVAL;
+  if (!p.w || !p.dst0 || p.Kpad < p.Cin || (p.Kpad & 3)) return MSEG_EINVAL;
+  if (p.NB <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0) return MSEG_EINVAL;
+  if (p.KH <= 0 || p.KW <= 0 || p.KH * p.KW > 16) return MSEG_EINVAL;
+  if (p.stride != 1 && p.stride != 2) return MSEG_EINVAL;
+  if (p.mode != MSEG_MODE_CONV && p.mode != MSEG_MODE_TCONV) return MSEG_EINVAL;
+  if (p.morder == MSEG_MORDER_PARITY && ((p.Ho | p.Wo) & 1)) return MSEG_EINVAL;
+  if (p.Ngemm <= 0) return MSEG_EINVAL;
+  if (p.epi == MSEG_EPI_SCATTER2X2) {
+    if (p.Cq <= 0 || p.Ngemm != 4 * p.Cq || p.morder != MSEG_MORDER_LINEAR) return MSEG_EINVAL;
+  } else if (p.epi == MSEG_EPI_PLAIN) {
+    if (p.split < p.Ngemm && !p.dst1) return MSEG_EINVAL;
+  } else {
+    return MSEG_EINVAL;
+  }
+  const long long M = (long long)p.NB * p.Ho * p.Wo;
+  if (M <= 0 || M > 0x7fffffffLL) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.Ngemm > 64) {
+    const long long tiles = ((M + 127) / 128) * ((p.Ngemm + 127) / 128);
+    if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
+    hipLaunchKernelGGL((igemm_kernel<128, 128>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  } else {
+    const long long tiles = ((M + 255) / 256);
+    hipLaunchKernelGGL((igemm_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  }
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- weight repack ------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int R, int C,
+                                   int Cpad, int st, int sr, int sc) {
+  const size_t total = (size_t)T * R * Cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const size_t tr = i / Cpad;
+    const int r = (int)(tr % R);
+    const int t = (int)(tr / R);
+    dst[i] = c < C ? src[(size_t)t * st + (size_t)r * sr + (size_t)c * sc] : 0.f;
+  }
+}
+
+extern "C" int mseg_pack_weight(const float* src, float* dst, int T, int R, int C, int Cpad, int st, int sr, int sc,
+                                void* stream) {
+  if (!src || !dst || T <= 0 || R <= 0 || C <= 0 || Cpad < C || (Cpad & 3)) return MSEG_EINVAL;
+  const size_t total = (size_t)T * R * Cpad;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096u) blocks = 4096u;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, T, R, C, Cpad, st,
+                     sr, sc);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -1,0 +1,227 @@
+// loss.hip — training losses of src/training/losses.py as fused forward(+backward) HBM-bound kernels.
+//   distance method: nn.SmoothL1Loss / L1Loss / MSELoss per head (losses.py:24-32), summed at train.py:480-482
+//   boundary method: ce_dice = CrossEntropy + 0.5 * sum_{c=1,2} c * Dice_c (losses.py:71-97, dice_loss :40-68)
+// Reductions are fp64 with a fixed two-stage order (deterministic).
+#include "common.h"
+
+#define LOSS_BLOCKS 1024
+
+extern "C" size_t mseg_loss_workspace_bytes(size_t n) {
+  (void)n;
+  return (size_t)LOSS_BLOCKS * 8 * sizeof(double);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+
+__device__ __forceinline__ float reg_loss(float d, int kind) {
+  const float ad = fabsf(d);
+  if (kind == 0) return ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+  if (kind == 1) return ad;
+  return d * d;
+}
+
+__device__ __forceinline__ float reg_grad(float d, int kind) {
+  if (kind == 0) return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+  if (kind == 1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  return 2.f * d;
+}
+
+__global__ __launch_bounds__(256) void reg_loss_partial_kernel(const float* __restrict__ pred,
+                                                               const float* __restrict__ target, size_t n, int kind,
+                                                               double* __restrict__ part) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s += (double)reg_loss(pred[i] - target[i], kind);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void reg_loss_final_kernel(const double* __restrict__ part, int nparts, size_t n,
+                                                             float* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = (float)(s / (double)n);
+}
+
+__global__ void reg_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n,
+                                    int kind, const float* __restrict__ gscale, float* __restrict__ grad) {
+  const float gs = (gscale ? gscale[0] : 1.f) / (float)n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    grad[i] = gs * reg_grad(pred[i] - target[i], kind);
+}
+
+static unsigned loss_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > LOSS_BLOCKS ? LOSS_BLOCKS : b);
+}
+
+extern "C" int mseg_regression_loss(const float* pred, const float* target, size_t n, int kind, float* loss_out,
+                                    void* ws, void* stream) {
+  if (!pred || !target || !loss_out || !ws || n == 0 || kind < 0 || kind > 2) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = loss_blocks(n);
+  hipLaunchKernelGGL(reg_loss_partial_kernel, dim3(nb), dim3(256), 0, st, pred, target, n, kind, (double*)ws);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reg_loss_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, (int)nb, n, loss_out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_regression_loss_bwd(const float* pred, const float* target, size_t n, int kind,
+                                        const float* gscale_dev, float* grad, void* stream) {
+  if (!pred || !target || !grad || n == 0 || kind < 0 || kind > 2) return MSEG_EINVAL;
+  hipLaunchKernelGGL(reg_loss_bwd_kernel, dim3(loss_blocks(n) * 4), dim3(256), 0, (hipStream_t)stream, pred, target,
+                     n, kind, gscale_dev, grad);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- ce_dice ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void softmax3(float l0, float l1, float l2, float& p0, float& p1, float& p2, float& lse) {
+  const float m = fmaxf(l0, fmaxf(l1, l2));
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+  const float s = e0 + e1 + e2;
+  p0 = e0 / s; p1 = e1 / s; p2 = e2 / s;
+  lse = m + logf(s);
+}
+
+// part[block][7] = {sum g1 p1, sum p1^2, sum g1, sum g2 p2, sum p2^2, sum g2, sum CE}
+__global__ __launch_bounds__(256) void ce_dice_partial_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ labels, int N, int HW,
+                                                              double* __restrict__ part) {
+  __shared__ double sh[4];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i - n * HW;
+    const float* l = logits + n * 3 * (size_t)HW + p;
+    const float l0 = l[0], l1 = l[HW], l2 = l[2 * (size_t)HW];
+    float p0, p1, p2, lse;
+    softmax3(l0, l1, l2, p0, p1, p2, lse);
+    const int y = (int)labels[i];
+    const float ly = y == 0 ? l0 : (y == 1 ? l1 : l2);
+    acc[6] += (double)(lse - ly);
+    acc[1] += (double)p1 * p1;
+    acc[4] += (double)p2 * p2;
+    if (y == 1) { acc[0] += p1; acc[2] += 1.0; }
+    if (y == 2) { acc[3] += p2; acc[5] += 1.0; }
+  }
+  for (int k = 0; k < 7; ++k) {
+    const double s = block_sum(acc[k], sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * 8 + k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_dice_final_kernel(const double* __restrict__ part, int nparts,
+                                                            double* __restrict__ sums6, double* __restrict__ ce_sum) {
+  __shared__ double sh[4];
+  for (int k = 0; k < 7; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[(size_t)i * 8 + k];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+      if (k < 6) sums6[k] = s;
+      else ce_sum[0] = s;
+    }
+  }
+}
+
+extern "C" int mseg_ce_dice_fwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice,
+                                double* sums6, double* ce_sum, void* ws, void* stream) {
+  (void)with_dice;
+  if (!logits || !labels || !sums6 || !ce_sum || !ws || N <= 0 || HW <= 0) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = loss_blocks((size_t)N * HW);
+  hipLaunchKernelGGL(ce_dice_partial_kernel, dim3(nb), dim3(256), 0, st, logits, labels, N, HW, (double*)ws);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_dice_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, (int)nb, sums6, ce_sum);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// d/dlogit_k [ CE_mean + 0.5 * sum_c c * (1 - (2 I_c + 1)/(G_c + P_c + 1)) ]
+__global__ void ce_dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N,
+                                   int HW, int with_dice, const double* __restrict__ sums6, double total_px,
+                                   const float* __restrict__ gscale, float* __restrict__ grad) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  float A[3] = {0, 0, 0}, B[3] = {1, 1, 1};
+  if (with_dice) {
+    for (int c = 1; c <= 2; ++c) {
+      const double I = sums6[(c - 1) * 3 + 0], P = sums6[(c - 1) * 3 + 1], G = sums6[(c - 1) * 3 + 2];
+      A[c] = (float)(2.0 * I + 1.0);
+      B[c] = (float)(G + P + 1.0);
+    }
+  }
+  const float inv_total = (float)(1.0 / total_px);
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i - n * HW;
+    const float* l = logits + n * 3 * (size_t)HW + p;
+    float pr[3], lse;
+    softmax3(l[0], l[HW], l[2 * (size_t)HW], pr[0], pr[1], pr[2], lse);
+    const int y = (int)labels[i];
+    float g[3];
+    for (int k = 0; k < 3; ++k) g[k] = (pr[k] - (y == k ? 1.f : 0.f)) * inv_total;
+    if (with_dice) {
+      // dDice_c/dp_c = -2 g_c / B_c + 2 A_c p_c / B_c^2 ;  dp_c/dlogit_k = p_c (delta_ck - p_k)
+      for (int c = 1; c <= 2; ++c) {
+        const float gc = (y == c) ? 1.f : 0.f;
+        const float D = 0.5f * (float)c * (-2.f * gc / B[c] + 2.f * A[c] * pr[c] / (B[c] * B[c]));
+        for (int k = 0; k < 3; ++k) g[k] += D * pr[c] * ((k == c ? 1.f : 0.f) - pr[k]);
+      }
+    }
+    float* go = grad + n * 3 * (size_t)HW + p;
+    go[0] = gs * g[0]; go[HW] = gs * g[1]; go[2 * (size_t)HW] = gs * g[2];
+  }
+}
+
+extern "C" int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice,
+                                const double* sums6, double total_px, const float* gscale_dev, float* grad,
+                                void* stream) {
+  if (!logits || !labels || !sums6 || !grad || N <= 0 || HW <= 0 || total_px <= 0.0) return MSEG_EINVAL;
+  hipLaunchKernelGGL(ce_dice_bwd_kernel, dim3(loss_blocks((size_t)N * HW) * 4), dim3(256), 0, (hipStream_t)stream,
+                     logits, labels, N, HW, with_dice, sums6, total_px, gscale_dev, grad);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- Adam (amsgrad) — torch.optim.Adam(lr 8e-4, betas (0.9, 0.999), eps 1e-8, amsgrad=True): train.py:380-385 ----
+__global__ void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, float* __restrict__ vmax, size_t n, float lr, float beta1,
+                                    float beta2, float eps, float bc1, float bc2_sqrt) {
+  const float step_size = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float vm = fmaxf(vmax[i], vi);
+    m[i] = mi; v[i] = vi; vmax[i] = vm;
+    const float denom = sqrtf(vm) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
+                                      float beta1, float beta2, float eps, int step, void* stream) {
+  if (!p || !g || !m || !v || !vmax || n == 0 || step < 1) return MSEG_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(loss_blocks(n) * 2), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
+                     n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -1,0 +1,352 @@
+// norm.hip — BatchNorm2d / GroupNorm(8) / InstanceNorm2d applied AFTER the activation, as in the reference blocks
+// conv -> act -> norm (src/utils/unets.py:111-134,189-212) and convT -> norm (unets.py:244-262).
+//
+// HBM-bound kernels.  The forward never writes a normalised tensor: it reduces a = act(z) to per-(sample,channel)
+// fp64 sums (one read of z), and a tiny finalize turns them into scale/shift tables that the *consumer* kernels
+// apply while loading (MsegSrc, "norm-on-load").  The backward is one reduction pass + one elementwise pass.
+// Layout NHWC: a thread owns 4 consecutive channels and walks pixels, so reads are 16 B/lane coalesced and the
+// channel reduction needs no shuffles across lanes; partial sums meet in LDS (fp64) and then in a fixed-order
+// second stage (deterministic, no atomics).
+#include "common.h"
+
+struct NormGeom {
+  int N, HW, C, chunks, rows_per_chunk;
+};
+
+static NormGeom norm_geom(int N, int HW, int C) {
+  NormGeom g;
+  g.N = N; g.HW = HW; g.C = C;
+  int maxc = 2048 / (N > 0 ? N : 1);
+  if (maxc < 1) maxc = 1;
+  int chunks = HW / 512;
+  if (chunks > maxc) chunks = maxc;
+  if (chunks < 1) chunks = 1;
+  g.rows_per_chunk = (HW + chunks - 1) / chunks;
+  g.chunks = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
+  return g;
+}
+
+extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  NormGeom g = norm_geom(N, HW, C);
+  // fp64 partials [N][chunks][3][C] + per-(n,c) sums [3][N][C] + fp32 k-tables [3][N][C] (2*N*C doubles)
+  return ((size_t)N * g.chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
+}
+
+// MODE 0: forward  sums of (a, a*a)           from z
+// MODE 1: backward sums of (gy, gy*a)         from (gy, z)
+// MODE 2: backward apply: dz = (k1*gy + k2*a + k3) * act'(z), sums of (dz)
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                        float* __restrict__ dz, const float* __restrict__ k1,
+                                                        const float* __restrict__ k2, const float* __restrict__ k3,
+                                                        int kss, NormGeom g, int act, double* __restrict__ part) {
+  __shared__ double red[256 * 8];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int C4 = g.C >> 2;
+  const int CW = C4 < 256 ? C4 : 256;
+  const int rpi = 256 / CW;
+  const int cq = tid % CW, r0 = tid / CW;
+  const int row_begin = chunk * g.rows_per_chunk;
+  int row_end = row_begin + g.rows_per_chunk;
+  if (row_end > g.HW) row_end = g.HW;
+  constexpr int NS = (MODE == 2) ? 1 : 2;
+  double* pout = part + ((size_t)n * g.chunks + chunk) * 3 * g.C;
+
+  for (int cbase = 0; cbase < C4; cbase += CW) {
+    const int c4 = cbase + cq;
+    const bool active = (c4 < C4) && (r0 < rpi);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (active) {
+      const int c = c4 * 4;
+      float4 a1 = make_float4(0, 0, 0, 0), a2 = a1, a3 = a1;
+      if (MODE == 2) {
+        a1 = *reinterpret_cast<const float4*>(k1 + (size_t)n * kss + c);
+        a2 = *reinterpret_cast<const float4*>(k2 + (size_t)n * kss + c);
+        a3 = *reinterpret_cast<const float4*>(k3 + (size_t)n * kss + c);
+      }
+      for (int r = row_begin + r0; r < row_end; r += rpi) {
+        const size_t off = ((size_t)n * g.HW + r) * g.C + c;
+        const float4 zv = *reinterpret_cast<const float4*>(z + off);
+        const float4 av = act_fwd4(zv, act);
+        if (MODE == 0) {
+          s0[0] += av.x; s0[1] += av.y; s0[2] += av.z; s0[3] += av.w;
+          s1[0] += (double)av.x * av.x; s1[1] += (double)av.y * av.y;
+          s1[2] += (double)av.z * av.z; s1[3] += (double)av.w * av.w;
+        } else {
+          const float4 gv = *reinterpret_cast<const float4*>(gy + off);
+          if (MODE == 1) {
+            s0[0] += gv.x; s0[1] += gv.y; s0[2] += gv.z; s0[3] += gv.w;
+            s1[0] += (double)gv.x * av.x; s1[1] += (double)gv.y * av.y;
+            s1[2] += (double)gv.z * av.z; s1[3] += (double)gv.w * av.w;
+          } else {
+            float4 d;
+            d.x = (a1.x * gv.x + a2.x * av.x + a3.x) * act_bwd(zv.x, act);
+            d.y = (a1.y * gv.y + a2.y * av.y + a3.y) * act_bwd(zv.y, act);
+            d.z = (a1.z * gv.z + a2.z * av.z + a3.z) * act_bwd(zv.z, act);
+            d.w = (a1.w * gv.w + a2.w * av.w + a3.w) * act_bwd(zv.w, act);
+            *reinterpret_cast<float4*>(dz + off) = d;
+            s0[0] += d.x; s0[1] += d.y; s0[2] += d.z; s0[3] += d.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[tid * 8 + j] = s0[j];
+      red[tid * 8 + 4 + j] = s1[j];
+    }
+    __syncthreads();
+    if (r0 == 0 && c4 < C4) {
+      double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+      for (int k = 0; k < rpi; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t0[j] += red[(k * CW + cq) * 8 + j];
+          t1[j] += red[(k * CW + cq) * 8 + 4 + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pout[c4 * 4 + j] = t0[j];
+        if (NS == 2) pout[g.C + c4 * 4 + j] = t1[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// nc[s][n][c] = sum over chunks of part[n][chunk][s][c]
+__global__ void norm_reduce_chunks_kernel(const double* __restrict__ part, double* __restrict__ nc, NormGeom g,
+                                          int ns) {
+  const int total = ns * g.N * g.C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % g.C;
+    const int n = (i / g.C) % g.N;
+    const int s = i / (g.C * g.N);
+    double acc = 0.0;
+    for (int k = 0; k < g.chunks; ++k) acc += part[(((size_t)n * g.chunks + k) * 3 + s) * g.C + c];
+    nc[((size_t)s * g.N + n) * g.C + c] = acc;
+  }
+}
+
+// forward finalize: statistics -> scale/shift tables (+ saved mean/rstd, BN running stats)
+__global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum) {
+  const double* S = nc;
+  const double* Q = nc + (size_t)g.N * g.C;
+  if (norm == MSEG_NORM_BN) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+      double s = 0.0, q = 0.0;
+      for (int n = 0; n < g.N; ++n) { s += S[(size_t)n * g.C + c]; q += Q[(size_t)n * g.C + c]; }
+      const double cnt = (double)g.N * g.HW;
+      const double mean = s / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(var + (double)eps);
+      const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+      scale[c] = (float)(ga * rstd);
+      shift[c] = (float)(be - mean * ga * rstd);
+      mean_out[c] = (float)mean;
+      rstd_out[c] = (float)rstd;
+      if (running_mean) {
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * running_var[c] + (double)momentum * unb);
+      }
+    }
+    return;
+  }
+  const int groups = (norm == MSEG_NORM_GN) ? 8 : g.C;
+  const int cg = g.C / groups;
+  const int total = g.N * g.C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % g.C, n = i / g.C;
+    const int grp = c / cg;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      s += S[(size_t)n * g.C + grp * cg + k];
+      q += Q[(size_t)n * g.C + grp * cg + k];
+    }
+    const double cnt = (double)cg * g.HW;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double ga = (norm == MSEG_NORM_GN && gamma) ? (double)gamma[c] : 1.0;
+    const double be = (norm == MSEG_NORM_GN && beta) ? (double)beta[c] : 0.0;
+    scale[i] = (float)(ga * rstd);
+    shift[i] = (float)(be - mean * ga * rstd);
+    if (c == grp * cg) {
+      mean_out[n * groups + grp] = (float)mean;
+      rstd_out[n * groups + grp] = (float)rstd;
+    }
+  }
+}
+
+// backward finalize: per-(n,c) sums of gy and gy*a -> k1,k2,k3 tables, dgamma, dbeta
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
+                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, float* __restrict__ k1,
+                                         float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta) {
+  const double* S1 = nc;                        // sum gy
+  const double* S2 = nc + (size_t)g.N * g.C;    // sum gy*a
+  if (norm == MSEG_NORM_BN) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int n = 0; n < g.N; ++n) { s1 += S1[(size_t)n * g.C + c]; s2 += S2[(size_t)n * g.C + c]; }
+      const double cnt = (double)g.N * g.HW;
+      const double mu = mean[c], r = rstd[c], ga = gamma ? (double)gamma[c] : 1.0;
+      const double sx = r * (s2 - mu * s1);  // sum gy * xhat
+      const double m1 = ga * s1 / cnt, m2 = ga * sx / cnt;
+      k1[c] = (float)(ga * r);
+      k2[c] = (float)(-r * r * m2);
+      k3[c] = (float)(-r * m1 + r * r * m2 * mu);
+      if (dgamma) dgamma[c] = (float)sx;
+      if (dbeta) dbeta[c] = (float)s1;
+    }
+    return;
+  }
+  const int groups = (norm == MSEG_NORM_GN) ? 8 : g.C;
+  const int cg = g.C / groups;
+  const int total = g.N * g.C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % g.C, n = i / g.C;
+    const int grp = c / cg;
+    const double mu = mean[n * groups + grp], r = rstd[n * groups + grp];
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      const int cc = grp * cg + k;
+      const double ga = (norm == MSEG_NORM_GN && gamma) ? (double)gamma[cc] : 1.0;
+      const double s1 = S1[(size_t)n * g.C + cc], s2 = S2[(size_t)n * g.C + cc];
+      m1 += ga * s1;
+      m2 += ga * r * (s2 - mu * s1);
+    }
+    const double cnt = (double)cg * g.HW;
+    m1 /= cnt; m2 /= cnt;
+    const double gac = (norm == MSEG_NORM_GN && gamma) ? (double)gamma[c] : 1.0;
+    k1[i] = (float)(gac * r);
+    k2[i] = (float)(-r * r * m2);
+    k3[i] = (float)(-r * m1 + r * r * m2 * mu);
+  }
+  if (norm == MSEG_NORM_GN && dgamma) {
+    // dgamma_c = sum_n rstd*(S2 - mean*S1), dbeta_c = sum_n S1   (one thread per channel, fixed order)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+      const int grp = c / cg;
+      double dg = 0.0, db = 0.0;
+      for (int n = 0; n < g.N; ++n) {
+        const double mu = mean[n * groups + grp], r = rstd[n * groups + grp];
+        const double s1 = S1[(size_t)n * g.C + c], s2 = S2[(size_t)n * g.C + c];
+        dg += r * (s2 - mu * s1);
+        db += s1;
+      }
+      dgamma[c] = (float)dg;
+      if (dbeta) dbeta[c] = (float)db;
+    }
+  }
+}
+
+// dbias[c] = sum_n nc[0][n][c]
+__global__ void norm_colsum_kernel(const double* __restrict__ nc, NormGeom g, float* __restrict__ out) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int n = 0; n < g.N; ++n) s += nc[(size_t)n * g.C + c];
+    out[c] = (float)s;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // torch eval-mode batch_norm: (x - running_mean) / sqrt(running_var + eps) * weight + bias
+  const float inv = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * inv;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
+                               const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                               float* running_mean, float* running_var, float momentum, void* ws, void* stream) {
+  if (!z || !scale || !shift || !mean || !rstd || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
+  if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
+  if (norm < 0 || norm > 2) return MSEG_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  NormGeom g = norm_geom(N, HW, C);
+  double* part = (double*)ws;
+  double* nc = part + (size_t)N * g.chunks * 3 * C;
+  hipLaunchKernelGGL((norm_pass_kernel<0>), dim3(g.chunks, N), dim3(256), 0, st, z, (const float*)nullptr,
+                     (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
+                     part);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
+                     (const double*)part, nc, g, 2);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
+                     st, (const double*)nc, g, norm, gamma, beta, eps, scale, shift, mean, rstd, running_mean,
+                     running_var, momentum);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, int C, float* scale, float* shift,
+                                   void* stream) {
+  if (!running_mean || !running_var || !scale || !shift || C <= 0) return MSEG_EINVAL;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm,
+                             const float* gamma, const float* mean, const float* rstd, float* dz, float* dgamma,
+                             float* dbeta, float* dbias, void* ws, void* stream) {
+  if (!gy || !z || !mean || !rstd || !dz || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
+  if (norm < 0 || norm > 2) return MSEG_EINVAL;
+  if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  NormGeom g = norm_geom(N, HW, C);
+  double* part = (double*)ws;
+  double* nc = part + (size_t)N * g.chunks * 3 * C;
+  float* k1 = (float*)(nc + (size_t)3 * N * C);
+  float* k2 = k1 + (size_t)N * C;
+  float* k3 = k2 + (size_t)N * C;
+  const int kss = (norm == MSEG_NORM_BN) ? 0 : C;
+  hipLaunchKernelGGL((norm_pass_kernel<1>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, (float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act, part);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
+                     (const double*)part, nc, g, 2);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
+                     st, (const double*)nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta);
+  MSEG_LAUNCH_CHECK();
+  double* part2 = part;
+  hipLaunchKernelGGL((norm_pass_kernel<2>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, dz, (const float*)k1,
+                     (const float*)k2, (const float*)k3, kss, g, act, part2);
+  MSEG_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C)), dim3(256), 0, st,
+                       (const double*)part2, nc, g, 1);
+    MSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_colsum_kernel, dim3(nblocks(C)), dim3(256), 0, st, (const double*)nc, g, dbias);
+    MSEG_LAUNCH_CHECK();
+  }
+  return MSEG_OK;
+}

@@ -1,0 +1,459 @@
+"""Executor of the U-Net / dual-decoder U-Net hot path on libmseg_hip (gfx950).
+
+Host-side mirror of ``UNet.forward`` / ``DUNet.forward`` (reference: src/utils/unets.py:349-377, :463-506) and of
+their autograd backward (train.py:488).  Python only sequences kernels; every FLOP runs in the HIP library:
+
+* activations are NHWC fp32 and are kept in *pre-activation* form ``z = conv(x) + b``; the consumer applies
+  activation + Batch/Group/InstanceNorm while staging its operand ("norm-on-load"), so neither the activated nor
+  the normalised tensor, nor ``torch.cat([up, skip], 1)``, is ever written to HBM;
+* the backward pass is explicit (dgrad / wgrad / norm-bwd kernels) and is exposed to PyTorch as ONE
+  ``torch.autograd.Function`` so that ``loss.backward()`` and the stock optimizers keep working (plumbing only).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT, NORM, MODE_CONV, MODE_TCONV, EPI_PLAIN, EPI_SCATTER2X2, MORDER_LINEAR, MORDER_PARITY,
+                   MsegSrc, MsegIgemm, MsegWgrad, check)
+
+BN_EPS = 1e-5       # torch defaults used by the reference (unets.py:127-132)
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class Node:
+    """An activation tensor in pre-norm form plus the tables its consumers need to normalise it on load."""
+    __slots__ = ("z", "N", "H", "W", "C", "act", "norm", "scale", "shift", "ss", "mean", "rstd", "layer", "inputs",
+                 "grad")
+
+    def __init__(self, z, N, H, W, C):
+        self.z, self.N, self.H, self.W, self.C = z, N, H, W, C
+        self.act, self.norm = 0, None
+        self.scale = self.shift = self.mean = self.rstd = None
+        self.ss = 0
+        self.layer, self.inputs, self.grad = None, (), None
+
+    def src(self, transform=True):
+        s = MsegSrc()
+        s.ptr = self.z.data_ptr()
+        s.C = self.C
+        if transform:
+            s.act = self.act
+            s.scale = _ptr(self.scale)
+            s.shift = _ptr(self.shift)
+            s.ss = self.ss
+        return s
+
+
+def plain_src(t, C_):
+    s = MsegSrc()
+    s.ptr = t.data_ptr()
+    s.C = C_
+    return s
+
+
+class Workspace:
+    """Grow-only scratch buffers (the library never allocates; SURVEY.md §8b ownership)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = {}
+
+    def get(self, name, nbytes):
+        b = self.buf.get(name)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self.buf[name] = b
+        return b
+
+
+# ---- thin kernel wrappers ------------------------------------------------------------------------------------
+def pack_weight(src, T, R, Cc, Cpad, st, sr, sc):
+    lib = _lib.load()
+    dst = torch.empty(T * R * Cpad, dtype=torch.float32, device=src.device)
+    check(lib.mseg_pack_weight(src.data_ptr(), dst.data_ptr(), T, R, Cc, Cpad, st, sr, sc, _stream()), "pack_weight")
+    return dst
+
+
+def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, Kpad, dst0, ld0, acc0=0,
+          dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR):
+    lib = _lib.load()
+    p = MsegIgemm()
+    for i, s in enumerate(srcs):
+        p.src[i] = s
+    p.nsrc = len(srcs)
+    p.Cin = sum(s.C for s in srcs)
+    p.Kpad = Kpad
+    p.w = w.data_ptr()
+    p.bias = _ptr(bias)
+    p.dst0 = dst0.data_ptr()
+    p.dst1 = _ptr(dst1)
+    p.NB, p.Hi, p.Wi, p.Ho, p.Wo = NB, Hi, Wi, Ho, Wo
+    p.KH, p.KW, p.stride, p.pad, p.mode, p.morder = KH, KW, stride, pad, mode, morder
+    p.Ngemm, p.epi = Ngemm, epi
+    p.split = Ngemm if split is None else split
+    p.ld0, p.ld1, p.acc0, p.acc1, p.Cq = ld0, ld1, acc0, acc1, Cq
+    check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
+
+
+def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None):
+    lib = _lib.load()
+    p = MsegWgrad()
+    p.P = P
+    for i, s in enumerate(Qs):
+        p.Q[i] = s
+    p.nq = len(Qs)
+    p.Nch = sum(s.C for s in Qs)
+    p.Nch_store = p.Nch if nch_store is None else nch_store
+    p.NB, p.Hp, p.Wp, p.Hq, p.Wq = NB, Hp, Wp, Hq, Wq
+    p.KH, p.KW, p.stride, p.pad = KH, KW, stride, pad
+    p.splits = 0
+    p.dst = dst.data_ptr()
+    need = lib.mseg_wgrad_workspace_bytes(C.byref(p))
+    if need == 0:
+        raise RuntimeError("libmseg_hip wgrad: unsupported shape")
+    p.ws = ws.get("wgrad", need).data_ptr()
+    check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
+
+
+def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws):
+    """Fill node.scale/shift (+mean/rstd) from a = act(z); BatchNorm eval mode uses the running statistics."""
+    lib = _lib.load()
+    dev = node.z.device
+    node.norm = norm
+    N, HW, Cc = node.N, node.H * node.W, node.C
+    if norm == NORM["bn"]:
+        node.ss = 0
+        node.scale = torch.empty(Cc, dtype=torch.float32, device=dev)
+        node.shift = torch.empty(Cc, dtype=torch.float32, device=dev)
+        if not training:
+            check(lib.mseg_bn_eval_coeffs(_ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
+                                          BN_EPS, Cc, node.scale.data_ptr(), node.shift.data_ptr(), _stream()),
+                  "bn_eval_coeffs")
+            return
+        node.mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        node.rstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+    else:
+        node.ss = Cc
+        node.scale = torch.empty(N * Cc, dtype=torch.float32, device=dev)
+        node.shift = torch.empty(N * Cc, dtype=torch.float32, device=dev)
+        ng = 8 if norm == NORM["gn"] else Cc
+        node.mean = torch.empty(N * ng, dtype=torch.float32, device=dev)
+        node.rstd = torch.empty(N * ng, dtype=torch.float32, device=dev)
+        running_mean = running_var = None
+    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
+    check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
+                              node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
+                              node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
+                              w.data_ptr(), _stream()), "norm_stats")
+
+
+def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):
+    """gy (dL/d normalised output) -> dz in place; returns the same tensor holding dz."""
+    lib = _lib.load()
+    N, HW, Cc = node.N, node.H * node.W, node.C
+    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
+    check(lib.mseg_norm_bwd(gy.data_ptr(), node.z.data_ptr(), N, HW, Cc, node.act, node.norm, _ptr(gamma),
+                            node.mean.data_ptr(), node.rstd.data_ptr(), gy.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+                            _ptr(dbias), w.data_ptr(), _stream()), "norm_bwd")
+    return gy
+
+
+# ---- layer descriptions (built by utils/unets.py from the nn.Module tree) ------------------------------------
+class ConvSpec:
+    """conv (3x3 s1 | 3x3 s2 | convT 2x2 s2) -> activation -> norm, parameters held by stock torch modules."""
+
+    def __init__(self, kind, conv, norm_mod, act, norm):
+        self.kind = kind            # 'conv' | 'pool' | 'up'
+        self.conv = conv            # nn.Conv2d / nn.ConvTranspose2d (parameter holder)
+        self.norm_mod = norm_mod    # nn.BatchNorm2d / nn.GroupNorm / nn.InstanceNorm2d
+        self.act = ACT[act]
+        self.norm = NORM[norm]
+
+    def params(self):
+        ps = [self.conv.weight, self.conv.bias]
+        if self.norm in (NORM["bn"], NORM["gn"]):
+            ps += [self.norm_mod.weight, self.norm_mod.bias]
+        return ps
+
+
+class HeadSpec:
+    def __init__(self, conv):
+        self.conv = conv
+
+    def params(self):
+        return [self.conv.weight, self.conv.bias]
+
+
+class NetSpec:
+    def __init__(self, ch_in, enc, decoders, pool_method):
+        self.ch_in = ch_in
+        self.enc = enc              # list of dict(c1=ConvSpec, c2=ConvSpec, pool=ConvSpec|None)
+        self.decoders = decoders    # list (1 for U, 2 for DU) of dict(levels=[dict(up,c1,c2)], head=HeadSpec)
+        self.pool_method = pool_method
+
+    def layers(self):
+        out = []
+        for e in self.enc:
+            out += [e["c1"], e["c2"]]
+            if e["pool"] is not None:
+                out.append(e["pool"])
+        for d in self.decoders:
+            for lv in d["levels"]:
+                out += [lv["up"], lv["c1"], lv["c2"]]
+            out.append(d["head"])
+        return out
+
+    def params(self):
+        ps = []
+        for l in self.layers():
+            ps += l.params()
+        return ps
+
+
+# ---- forward ---------------------------------------------------------------------------------------------------
+class Tape:
+    """What the backward needs: nodes in execution order + head records."""
+
+    def __init__(self):
+        self.nodes = []
+        self.heads = []
+        self.x4 = None
+
+
+def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
+    conv = spec.conv
+    n0 = in_nodes[0]
+    N, Hi, Wi = n0.N, n0.H, n0.W
+    dev = n0.z.device
+    cin_total = sum(n.C for n in in_nodes)
+    srcs = [n.src() for n in in_nodes]
+    bias = conv.bias.detach()
+    wt = conv.weight.detach()
+    if spec.kind == "up":
+        cin, cout = wt.shape[0], wt.shape[1]
+        assert cin == cin_total
+        kp = _pad4(cin)
+        wp = pack_weight(wt, 4, cout, cin, kp, 1, 4, cout * 4)
+        Ho, Wo = 2 * Hi, 2 * Wi
+        z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+        igemm(srcs, wp, bias, N, Hi, Wi, Hi, Wi, 1, 1, 1, 0, MODE_CONV, 4 * cout, kp, z, cout,
+              epi=EPI_SCATTER2X2, Cq=cout)
+        act = ACT["none"]
+    else:
+        cout, cin = wt.shape[0], wt.shape[1]
+        stride = 2 if spec.kind == "pool" else 1
+        if first_layer_cin is None:
+            assert cin == cin_total, (cin, cin_total)
+        else:
+            assert _pad4(cin) == cin_total, (cin, cin_total)   # network input is zero-padded to 4 channels
+        kp = _pad4(cin_total)
+        wp = pack_weight(wt, 9, cout, cin, kp, 1, cin * 9, 9)
+        Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+        z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, kp, z, cout)
+        act = spec.act
+    node = Node(z, N, Ho, Wo, cout)
+    node.act = act
+    node.layer = spec
+    node.inputs = tuple(in_nodes)
+    nm = spec.norm_mod
+    if spec.norm == NORM["bn"]:
+        norm_stats(node, spec.norm, nm.weight.detach(), nm.bias.detach(), nm.running_mean, nm.running_var,
+                   training, ws)
+        if training:
+            nm.num_batches_tracked.add_(1)
+    elif spec.norm == NORM["gn"]:
+        norm_stats(node, spec.norm, nm.weight.detach(), nm.bias.detach(), None, None, training, ws)
+    else:
+        norm_stats(node, spec.norm, None, None, None, None, training, ws)
+    if tape is not None:
+        tape.nodes.append(node)
+    return node
+
+
+def forward(spec, x, training, keep_tape, ws):
+    """x: (N, ch_in, H, W) fp32 CUDA tensor.  Returns (list of NCHW outputs, Tape|None)."""
+    lib = _lib.load()
+    N, cin, H, W = x.shape
+    nlev = len(spec.enc)
+    div = 2 ** (nlev - 1)
+    if H % div or W % div:
+        raise RuntimeError(f"input {H}x{W} is not divisible by {div}")
+    if spec.pool_method != "conv":
+        raise NotImplementedError("pool_method='max' is not implemented on the HIP path yet")
+    dev = x.device
+    c4 = _pad4(cin)
+    x4 = torch.zeros((N, H, W, c4), dtype=torch.float32, device=dev)
+    x4[..., :cin] = x.detach().permute(0, 2, 3, 1)
+    xin = Node(x4, N, H, W, c4)
+    tape = Tape() if keep_tape else None
+    if tape is not None:
+        tape.x4 = xin
+
+    cur = xin
+    skips = []
+    for i, e in enumerate(spec.enc):
+        cur = _run_conv(e["c1"], [cur], training, ws, tape, first_layer_cin=cin if i == 0 else None)
+        cur = _run_conv(e["c2"], [cur], training, ws, tape)
+        if e["pool"] is not None:
+            skips.append(cur)
+            cur = _run_conv(e["pool"], [cur], training, ws, tape)
+    bottom = cur
+    outs = []
+    for d in spec.decoders:
+        cur = bottom
+        for lv, skip in zip(d["levels"], reversed(skips)):
+            up = _run_conv(lv["up"], [cur], training, ws, tape)
+            cur = _run_conv(lv["c1"], [up, skip], training, ws, tape)
+            cur = _run_conv(lv["c2"], [cur], training, ws, tape)
+        hc = d["head"].conv
+        co = hc.weight.shape[0]
+        out = torch.empty((N, co, H, W), dtype=torch.float32, device=dev)
+        s = cur.src()
+        check(lib.mseg_head_fwd(C.byref(s), N, H * W, hc.weight.detach().data_ptr(), hc.bias.detach().data_ptr(), co,
+                                out.data_ptr(), _stream()), "head_fwd")
+        outs.append(out)
+        if tape is not None:
+            tape.heads.append((d["head"], cur))
+    return outs, tape
+
+
+# ---- backward --------------------------------------------------------------------------------------------------
+def _accumulate_target(node, shape_like):
+    """Return (tensor, acc_flag) for writing a gradient contribution into node.grad."""
+    if node.grad is None:
+        node.grad = torch.empty_like(node.z)
+        return node.grad, 0
+    return node.grad, 1
+
+
+def backward(spec, tape, grad_outs, ws):
+    """grad_outs: list of NCHW gradients (None allowed) matching the forward outputs.  Returns {id(param): grad}."""
+    lib = _lib.load()
+    grads = {}
+    # heads
+    for (head, node), go in zip(tape.heads, grad_outs):
+        hc = head.conv
+        co = hc.weight.shape[0]
+        if go is None:
+            go = torch.zeros((node.N, co, node.H, node.W), dtype=torch.float32, device=node.z.device)
+        go = go.contiguous()
+        gy = torch.empty_like(node.z)
+        dW = torch.empty_like(hc.weight)
+        db = torch.empty_like(hc.bias)
+        w = ws.get("head", lib.mseg_head_bwd_workspace_bytes(node.N, node.H * node.W, node.C, co))
+        s = node.src()
+        check(lib.mseg_head_bwd(C.byref(s), node.N, node.H * node.W, hc.weight.detach().data_ptr(), co,
+                                go.data_ptr(), gy.data_ptr(), dW.data_ptr(), db.data_ptr(), w.data_ptr(), _stream()),
+              "head_bwd")
+        assert node.grad is None
+        node.grad = gy
+        grads[id(hc.weight)] = dW
+        grads[id(hc.bias)] = db
+
+    for node in reversed(tape.nodes):
+        sp = node.layer
+        conv = sp.conv
+        gy = node.grad
+        node.grad = None
+        if gy is None:
+            raise RuntimeError("internal: node without gradient")
+        nm = sp.norm_mod
+        has_affine = sp.norm in (NORM["bn"], NORM["gn"])
+        dgamma = torch.empty_like(nm.weight) if has_affine else None
+        dbeta = torch.empty_like(nm.bias) if has_affine else None
+        dbias = torch.empty_like(conv.bias)
+        dz = norm_bwd(node, gy, nm.weight.detach() if has_affine else None, dgamma, dbeta, dbias, ws)
+        if has_affine:
+            grads[id(nm.weight)] = dgamma
+            grads[id(nm.bias)] = dbeta
+        grads[id(conv.bias)] = dbias
+        wt = conv.weight.detach()
+        dW = torch.empty_like(wt)
+        ins = node.inputs
+        i0 = ins[0]
+        N = node.N
+        if sp.kind == "up":
+            cin, cout = wt.shape[0], wt.shape[1]
+            # dW[ci][co][a][b] = sum x[p][ci] * dz[2p+(a,b)][co]
+            wgrad(i0.src(), [plain_src(dz, cout)], dW, N, i0.H, i0.W, node.H, node.W, 2, 2, 2, 0, ws)
+            # dx[p][ci] = sum_{ab,co} dz[2p+(a,b)][co] * W[ci][co][a][b]
+            wp = pack_weight(wt, 4, cin, cout, _pad4(cout), 1, cout * 4, 4)
+            tgt, acc = _accumulate_target(i0, None)
+            igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 2, 2, 2, 0, MODE_CONV, cin,
+                  _pad4(cout), tgt, cin, acc0=acc)
+        else:
+            cout, cin = wt.shape[0], wt.shape[1]
+            stride = 2 if sp.kind == "pool" else 1
+            is_first = i0 is tape.x4
+            wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
+                  ws, nch_store=cin if is_first else None)
+            if not is_first:
+                wp = pack_weight(wt, 9, cin, cout, _pad4(cout), 1, 9, cin * 9)
+                morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
+                if len(ins) == 1:
+                    tgt, acc = _accumulate_target(i0, None)
+                    igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
+                          MODE_TCONV, cin, _pad4(cout), tgt, cin, acc0=acc, morder=morder)
+                else:
+                    i1 = ins[1]
+                    t0, a0 = _accumulate_target(i0, None)
+                    t1, a1 = _accumulate_target(i1, None)
+                    igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
+                          MODE_TCONV, cin, _pad4(cout), t0, i0.C, acc0=a0, dst1=t1, ld1=i1.C, acc1=a1,
+                          split=i0.C, morder=morder)
+        grads[id(conv.weight)] = dW
+        del dz, gy
+    return grads
+
+
+# ---- autograd glue -------------------------------------------------------------------------------------------
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        training = module.training
+        outs, tape = forward(module._spec, x, training, True, module._workspace(x.device))
+        ctx.module = module
+        ctx.tape = tape
+        ctx.nparams = len(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        module = ctx.module
+        tape = ctx.tape
+        if tape is None:
+            raise RuntimeError("backward through the HIP U-Net twice is not supported")
+        ctx.tape = None
+        grads = backward(module._spec, tape, list(grad_outs), module._workspace(tape.nodes[0].z.device))
+        plist = module._spec.params()
+        return (None, None) + tuple(grads.get(id(p)) for p in plist)
+
+
+def run_module(module, x):
+    """Entry used by UNet/DUNet.forward: returns a tuple of NCHW outputs."""
+    if not x.is_cuda:
+        raise RuntimeError(
+            "microbeseg_amd: the U-Net runs on the MI355X HIP path only (got a CPU tensor); there is deliberately "
+            "no CPU fallback in the product path — use the oracle under oracle/ for CPU reference runs")
+    _lib.load()
+    x = x.contiguous().float()
+    plist = module._spec.params()
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in plist)
+    if need_grad:
+        return _NetFunction.apply(module, x, *plist)
+    outs, _ = forward(module._spec, x, module.training, False, module._workspace(x.device))
+    return tuple(outs)

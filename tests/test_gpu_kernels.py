@@ -1,0 +1,278 @@
+"""GPU (MI355X): each HIP kernel of libmseg_hip through the C ABI vs a plain PyTorch fp32 CPU reference of the same op.
+Tolerance: 1e-4 relative (BASELINE.json north_star: "distance maps within 1e-4 relative fp32")."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd import engine, _lib
+    _lib.load()
+    return engine
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(g, *shape):
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def _act_cpu(x, act):
+    return {"none": lambda v: v, "relu": F.relu, "leakyrelu": lambda v: F.leaky_relu(v, 0.01),
+            "elu": F.elu, "mish": lambda v: v * torch.tanh(F.softplus(v))}[act](x)
+
+
+def _mk_node(eng, z_nchw, act="none", scale=None, shift=None, per_sample=False):
+    from microbeseg_amd._lib import ACT
+    N, Cc, H, W = z_nchw.shape
+    node = eng.Node(nhwc(z_nchw).cuda(), N, H, W, Cc)
+    node.act = ACT[act]
+    if scale is not None:
+        node.scale = scale.reshape(-1).cuda()
+        node.shift = shift.reshape(-1).cuda()
+        node.ss = Cc if per_sample else 0
+    return node
+
+
+def _transform_cpu(z, act, scale, shift, per_sample):
+    a = _act_cpu(z, act)
+    if scale is None:
+        return a
+    if per_sample:
+        return a * scale[:, :, None, None] + shift[:, :, None, None]
+    return a * scale[None, :, None, None] + shift[None, :, None, None]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride", [
+    (2, 8, 16, 16, 16, 1), (1, 64, 64, 32, 48, 1), (3, 16, 8, 20, 12, 1), (2, 32, 160, 16, 16, 1),
+    (2, 8, 8, 16, 32, 2), (1, 64, 64, 32, 32, 2), (2, 136, 72, 10, 14, 1),
+])
+@pytest.mark.parametrize("act", ["none", "mish"])
+def test_conv3x3_forward(eng, N, Cin, Cout, H, W, stride, act):
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, N, Cin) * 0.5 + 1.0, rnd(g, N, Cin) * 0.2
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_transform_cpu(z, act, scale, shift, True), w, b, stride=stride, padding=1)
+    node = _mk_node(eng, z, act, scale, shift, per_sample=True)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, Cin, 1, Cin * 9, 9)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, Cout, Cin, out, Cout)
+    assert rel_err(nchw(out.cpu()), ref) < TOL
+
+
+def test_conv3x3_concat_two_sources(eng):
+    g = torch.Generator().manual_seed(7)
+    N, C0, C1, Cout, H, W = 2, 8, 24, 40, 12, 20
+    z0, z1 = rnd(g, N, C0, H, W), rnd(g, N, C1, H, W)
+    s0, h0 = rnd(g, C0) * 0.3 + 1, rnd(g, C0) * 0.1
+    s1, h1 = rnd(g, N, C1) * 0.3 + 1, rnd(g, N, C1) * 0.1
+    w, b = rnd(g, Cout, C0 + C1, 3, 3) * 0.1, rnd(g, Cout)
+    x = torch.cat([_transform_cpu(z0, "none", s0, h0, False), _transform_cpu(z1, "relu", s1, h1, True)], 1)
+    ref = F.conv2d(x, w, b, padding=1)
+    n0 = _mk_node(eng, z0, "none", s0, h0, False)
+    n1 = _mk_node(eng, z1, "relu", s1, h1, True)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, C0 + C1, C0 + C1, 1, (C0 + C1) * 9, 9)
+    out = torch.empty((N, H, W, Cout), device="cuda")
+    eng.igemm([n0.src(), n1.src()], wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, C0 + C1, out, Cout)
+    assert rel_err(nchw(out.cpu()), ref) < TOL
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride", [(2, 8, 16, 16, 16, 1), (1, 32, 72, 12, 20, 1), (2, 16, 16, 16, 24, 2),
+                                                   (1, 64, 64, 32, 32, 2)])
+def test_conv3x3_dgrad(eng, N, Cin, Cout, H, W, stride):
+    """data gradient = TCONV mode; stride 2 uses the parity M-order (dead-tap skipping)."""
+    g = torch.Generator().manual_seed(11 + Cin)
+    x = rnd(g, N, Cin, H, W).requires_grad_(True)
+    w = rnd(g, Cout, Cin, 3, 3) * 0.1
+    y = F.conv2d(x, w, None, stride=stride, padding=1)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    ref = x.grad
+    wp = eng.pack_weight(w.cuda(), 9, Cin, Cout, Cout, 1, 9, Cin * 9)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dz = nhwc(gy).cuda()
+    out = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    morder = eng.MORDER_PARITY if stride == 2 else eng.MORDER_LINEAR
+    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, Cout, out, Cin,
+              morder=morder)
+    assert rel_err(nchw(out.cpu()), ref) < TOL
+    # accumulate flag + split destinations
+    base = rnd(g, N, H, W, Cin)
+    c0 = Cin // 2 // 4 * 4 or 4
+    d0, d1 = base[..., :c0].contiguous().cuda(), base[..., c0:].contiguous().cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, Cout, d0, c0,
+              acc0=1, dst1=d1, ld1=Cin - c0, acc1=0, split=c0, morder=morder)
+    refn = nhwc(ref)
+    assert rel_err(d0.cpu(), refn[..., :c0] + base[..., :c0]) < TOL
+    assert rel_err(d1.cpu(), refn[..., c0:]) < TOL
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 8, 8, 8), (1, 128, 64, 8, 12), (2, 32, 40, 6, 10)])
+def test_conv_transpose_forward_and_dgrad(eng, N, Cin, Cout, H, W):
+    g = torch.Generator().manual_seed(5 + Cin)
+    x = rnd(g, N, Cin, H, W).requires_grad_(True)
+    w, b = rnd(g, Cin, Cout, 2, 2) * 0.1, rnd(g, Cout)
+    y = F.conv_transpose2d(x, w, b, stride=2)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    node = _mk_node(eng, x.detach())
+    wp = eng.pack_weight(w.cuda(), 4, Cout, Cin, Cin, 1, 4, Cout * 4)
+    out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, Cin, out, Cout,
+              epi=eng.EPI_SCATTER2X2, Cq=Cout)
+    assert rel_err(nchw(out.cpu()), y.detach()) < TOL
+    wd = eng.pack_weight(w.cuda(), 4, Cin, Cout, Cout, 1, Cout * 4, 4)
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    dz = nhwc(gy).cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, 2 * H, 2 * W, H, W, 2, 2, 2, 0, eng.MODE_CONV, Cin, Cout, dx, Cin)
+    assert rel_err(nchw(dx.cpu()), x.grad) < TOL
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride", [(2, 8, 16, 16, 16, 1), (3, 72, 40, 10, 14, 1), (2, 16, 16, 16, 24, 2),
+                                                   (4, 64, 64, 32, 32, 1), (1, 136, 200, 9, 7, 1)])
+def test_conv3x3_wgrad(eng, N, Cin, Cout, H, W, stride):
+    g = torch.Generator().manual_seed(3 + Cout)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1, rnd(g, Cin) * 0.1
+    xin = _transform_cpu(z, "relu", scale, shift, False)
+    w = (rnd(g, Cout, Cin, 3, 3) * 0.1).requires_grad_(True)
+    y = F.conv2d(xin, w, None, stride=stride, padding=1)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    node = _mk_node(eng, z, "relu", scale, shift, False)
+    dz = nhwc(gy).cuda()
+    dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    ws = eng.Workspace(torch.device("cuda"))
+    eng.wgrad(eng.plain_src(dz, Cout), [node.src()], dW, N, y.shape[2], y.shape[3], H, W, 3, 3, stride, 1, ws)
+    assert rel_err(dW.cpu(), w.grad) < TOL
+
+
+def test_convT_wgrad(eng):
+    g = torch.Generator().manual_seed(9)
+    N, Cin, Cout, H, W = 2, 32, 24, 6, 10
+    x = rnd(g, N, Cin, H, W)
+    w = (rnd(g, Cin, Cout, 2, 2) * 0.1).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, stride=2)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    node = _mk_node(eng, x)
+    dz = nhwc(gy).cuda()
+    dW = torch.full((Cin, Cout, 2, 2), float("nan"), device="cuda")
+    ws = eng.Workspace(torch.device("cuda"))
+    eng.wgrad(node.src(), [eng.plain_src(dz, Cout)], dW, N, H, W, 2 * H, 2 * W, 2, 2, 2, 0, ws)
+    assert rel_err(dW.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("norm", ["bn", "gn", "in"])
+@pytest.mark.parametrize("act", ["relu", "mish", "elu", "leakyrelu", "none"])
+@pytest.mark.parametrize("N,Cc,H,W", [(3, 16, 12, 20), (2, 64, 32, 32)])
+def test_norm_forward_backward(eng, norm, act, N, Cc, H, W):
+    """norm(act(z)) statistics, scale/shift tables, running stats, and the full backward (dz, dgamma, dbeta, dbias)."""
+    from microbeseg_amd._lib import ACT, NORM
+    g = torch.Generator().manual_seed(17 + Cc)
+    z = (rnd(g, N, Cc, H, W) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (rnd(g, Cc) * 0.3 + 1).requires_grad_(True)
+    beta = (rnd(g, Cc) * 0.1).requires_grad_(True)
+    rm, rv = rnd(g, Cc) * 0.1, torch.rand(Cc, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a = _act_cpu(z, act)
+    if norm == "bn":
+        y = F.batch_norm(a, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    elif norm == "gn":
+        y = F.group_norm(a, 8, gamma, beta, 1e-5)
+    else:
+        y = F.instance_norm(a, eps=1e-5)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+
+    node = eng.Node(nhwc(z.detach()).cuda(), N, H, W, Cc)
+    node.act = ACT[act]
+    ws = eng.Workspace(torch.device("cuda"))
+    has_aff = norm != "in"
+    gm, bt = (gamma.detach().cuda(), beta.detach().cuda()) if has_aff else (None, None)
+    rmd, rvd = (rm.cuda(), rv.cuda()) if norm == "bn" else (None, None)
+    eng.norm_stats(node, NORM[norm], gm, bt, rmd, rvd, True, ws)
+    # the tables reproduce y when applied to a
+    sc = node.scale.cpu().reshape(-1, Cc)
+    sh = node.shift.cpu().reshape(-1, Cc)
+    y_hip = a.detach() * sc[:, :, None, None] + sh[:, :, None, None] if norm != "bn" else \
+        a.detach() * sc[0][None, :, None, None] + sh[0][None, :, None, None]
+    assert rel_err(y_hip, y.detach()) < TOL
+    if norm == "bn":
+        assert rel_err(rmd.cpu(), rm_ref) < 1e-5 and rel_err(rvd.cpu(), rv_ref) < 1e-5
+    gyd = nhwc(gy).cuda()
+    dgamma = torch.empty(Cc, device="cuda") if has_aff else None
+    dbeta = torch.empty(Cc, device="cuda") if has_aff else None
+    dbias = torch.empty(Cc, device="cuda")
+    dz = eng.norm_bwd(node, gyd, gm, dgamma, dbeta, dbias, ws)
+    scale_ref = z.grad.abs().max().item()
+    assert rel_err(nchw(dz.cpu()), z.grad) < TOL
+    assert rel_err(dbias.cpu(), z.grad.sum((0, 2, 3)), floor=1e-3 * scale_ref * H * W) < TOL
+    if has_aff:
+        assert rel_err(dgamma.cpu(), gamma.grad) < TOL
+        assert rel_err(dbeta.cpu(), beta.grad) < TOL
+
+
+def test_bn_eval_coeffs(eng):
+    from microbeseg_amd._lib import NORM
+    g = torch.Generator().manual_seed(1)
+    N, Cc, H, W = 2, 32, 8, 8
+    z = rnd(g, N, Cc, H, W)
+    gamma, beta, rm, rv = rnd(g, Cc), rnd(g, Cc), rnd(g, Cc), torch.rand(Cc, generator=g) + 0.5
+    ref = F.batch_norm(F.relu(z), rm, rv, gamma, beta, False, 0.1, 1e-5)
+    node = eng.Node(nhwc(z).cuda(), N, H, W, Cc)
+    node.act = 1
+    eng.norm_stats(node, NORM["bn"], gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), False, eng.Workspace("cuda"))
+    y = F.relu(z) * node.scale.cpu()[None, :, None, None] + node.shift.cpu()[None, :, None, None]
+    assert rel_err(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("Cc,Co", [(8, 1), (64, 3), (16, 2)])
+def test_head_forward_backward(eng, Cc, Co):
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(23 + Cc)
+    N, H, W = 2, 20, 12
+    z = rnd(g, N, Cc, H, W)
+    scale, shift = rnd(g, Cc) * 0.3 + 1, rnd(g, Cc) * 0.1
+    xin = _transform_cpu(z, "mish", scale, shift, False).requires_grad_(True)
+    w = (rnd(g, Co, Cc, 1, 1) * 0.2).requires_grad_(True)
+    b = rnd(g, Co).requires_grad_(True)
+    y = F.conv2d(xin, w, b)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    node = _mk_node(eng, z, "mish", scale, shift, False)
+    out = torch.empty((N, Co, H, W), device="cuda")
+    s = node.src()
+    wd, bd = w.detach().cuda(), b.detach().cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mseg_head_fwd(C.byref(s), N, H * W, wd.data_ptr(), bd.data_ptr(), Co, out.data_ptr(), stream))
+    assert rel_err(out.cpu(), y.detach()) < TOL
+    gx = torch.empty((N, H, W, Cc), device="cuda")
+    dW, db = torch.empty((Co, Cc), device="cuda"), torch.empty(Co, device="cuda")
+    wsb = torch.empty(lib.mseg_head_bwd_workspace_bytes(N, H * W, Cc, Co), dtype=torch.uint8, device="cuda")
+    god = gy.cuda()
+    _lib.check(lib.mseg_head_bwd(C.byref(s), N, H * W, wd.data_ptr(), Co, god.data_ptr(), gx.data_ptr(), dW.data_ptr(),
+                                 db.data_ptr(), wsb.data_ptr(), stream))
+    assert rel_err(nchw(gx.cpu()), xin.grad) < TOL
+    assert rel_err(dW.cpu(), w.grad.reshape(Co, Cc)) < TOL
+    assert rel_err(db.cpu(), b.grad) < TOL

@@ -1,0 +1,148 @@
+"""GPU (MI355X): the full HIP U-Net / DU-Net (forward, fused losses, explicit backward, optimizer steps) against
+  (a) golden vectors produced by the real reference modules (tests/golden/unet_*.npz, traj_*.npz), and
+  (b) the CPU oracle (oracle/unet_ref.py) on larger seeded inputs.
+Tolerance 1e-4 relative (BASELINE.json north_star)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _build(name, dev, sd):
+    from microbeseg_amd.utils.unets import build_unet
+    ut, act, norm, filters, ch_out, label_type = VARIANTS[name]
+    net = build_unet(ut, act, "conv", norm, dev, 1, ch_out=ch_out, filters=filters)
+    net.load_state_dict(sd)
+    return net
+
+
+def _loss(net, fx, label_type, dev, sfx=""):
+    from microbeseg_amd.training.losses import get_loss
+    x = torch.from_numpy(fx["x" + sfx[1:]] if sfx else fx["x"]).to(dev)
+    l1 = torch.from_numpy(fx["label1" + sfx]).to(dev)
+    if label_type == "distance":
+        crit = get_loss("smooth_l1", "distance")
+        l2 = torch.from_numpy(fx["label2" + sfx]).to(dev)
+        border, cell = net(x)
+        return crit["border"](border, l1) + crit["cell"](cell, l2), (border, cell)
+    crit = get_loss("ce_dice", "boundary")
+    out = net(x)
+    return crit(out, l1), (out,)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_net_matches_reference_fixture(name, dev):
+    label_type = VARIANTS[name][5]
+    fx = load_npz(f"unet_{name}.npz")
+    net = _build(name, dev, state_from(fx))
+    net.eval()
+    with torch.no_grad():
+        _, outs = _loss(net, fx, label_type, dev)
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu(), fx[f"eval_out{i}"]) < TOL, f"eval_out{i}"
+    net.train()
+    loss, outs = _loss(net, fx, label_type, dev)
+    for i, o in enumerate(outs):
+        assert rel_err(o.detach().cpu(), fx[f"train_out{i}"]) < TOL, f"train_out{i}"
+    assert abs(loss.item() - float(fx["loss"])) < TOL * max(1.0, abs(float(fx["loss"])))
+    loss.backward()
+    floor = grad_floor(fx)
+    params = dict(net.named_parameters())
+    for k, v in fx.items():
+        if k.startswith("g/"):
+            assert params[k[2:]].grad is not None, k
+            assert rel_err(params[k[2:]].grad.cpu(), v, floor) < 5 * TOL, k
+    sd = net.state_dict()
+    for k, v in fx.items():
+        if k.startswith("after/"):
+            assert np.allclose(sd[k[6:]].cpu().numpy(), v, rtol=1e-4, atol=1e-6), k
+
+
+def _traj(fxname, name, make_opt, steps, dev, tol_w):
+    label_type = VARIANTS[name][5]
+    fx = load_npz(fxname)
+    net = _build(name, dev, state_from(fx))
+    net.train()
+    opt = make_opt(net.parameters())
+    losses = []
+    for s in range(steps):
+        opt.zero_grad()
+        loss, _ = _loss(net, fx, label_type, dev, sfx=f"_{s % 2}")
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, fx["losses"], rtol=1e-3, atol=1e-5), (losses, fx["losses"])
+    sd = net.state_dict()
+    for k, v in fx.items():
+        if k.startswith("final/") and not k.endswith("num_batches_tracked"):
+            assert rel_err(sd[k[6:]].cpu(), v) < tol_w, k
+
+
+def test_adam_trajectory(dev):
+    _traj("traj_adam_DU_bn_relu.npz", "DU_bn_relu_8_16",
+          lambda ps: torch.optim.Adam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True), 8, dev,
+          5e-3)
+
+
+def test_ranger_trajectory(dev):
+    from microbeseg_amd.training.ranger2020 import Ranger
+    def mk(ps):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return Ranger(ps, lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6,
+                          weight_decay=0, use_gc=True, gc_conv_only=False, gc_loc=True)
+    _traj("traj_ranger_DU_bn_mish.npz", "DU_bn_mish_8_16", mk, 14, dev, 2e-2)
+
+
+def test_adam_ce_dice_trajectory(dev):
+    _traj("traj_adam_U_gn_relu.npz", "U_gn_relu_8_16",
+          lambda ps: torch.optim.Adam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True), 6, dev,
+          5e-3)
+
+
+@pytest.mark.parametrize("ut,act,norm,filters,size,batch", [
+    ("DU", "relu", "bn", (16, 128), 64, 3),      # 4 levels, odd batch
+    ("U", "mish", "gn", (32, 64), 96, 2),
+    ("DU", "relu", "bn", (64, 128), 48, 2),      # 64-channel level 0 like the default net
+])
+def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch, dev):
+    """Same seeded weights / inputs through the HIP net and the CPU oracle, forward + parameter gradients."""
+    from microbeseg_amd.utils.unets import build_unet
+    from oracle import unet_ref
+    torch.manual_seed(1234)
+    ch_out = 3 if ut == "U" else 1
+    net = build_unet(ut, act, "conv", norm, dev, 1, ch_out=ch_out, filters=filters)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(batch, 1, size, size) * 2 - 1
+    net.train()
+    outs = net(x.to(dev))
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    gos = [torch.randn(o.shape) for o in outs]
+    torch.autograd.backward(outs, [g.to(dev) for g in gos])
+
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    ref = unet_ref.unet_forward(params, x, ut, act, norm, filters, training=True, update_running_stats=True)
+    ref = ref if isinstance(ref, tuple) else (ref,)
+    torch.autograd.backward(ref, gos)
+    for o, r in zip(outs, ref):
+        assert rel_err(o.detach().cpu(), r.detach()) < TOL
+    floor = 1e-3 * max(p.grad.abs().max().item() for p in params.values() if getattr(p, "grad", None) is not None)
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), params[k].grad, floor) < 5 * TOL, k
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            assert rel_err(v.cpu(), params[k]) < 1e-4, k
