@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the microbeSEG hot path on MI355X: training crops/sec at 256x256.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1 via torch.distributed.run, RCCL)
+One "step" = zero_grad + forward + loss + backward (+ gradient all-reduce) + optimizer step on one per-GPU batch of
+synthetic crops that already live in HBM.  Workload at N=1 = BASELINE.json configs[1]: distance-method DU-Net
+`[64,1024]`, 256x256 crops, batch 32, fp32 (reference: train.py:184-194 + train_script.py defaults; ReLU/BatchNorm/
+Adam-amsgrad = the reference's Adam configuration, train.py:174,380-385).
+Prints ONE JSON line on rank 0 with `roofline` (dominant MFMA kernel, HIP-event timed inside the timed region) and
+`cpu_baseline` (the CPU oracle = port of the reference's torch path, bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
+# forward GFLOP per 256x256 crop, measured by hooking the reference modules (SURVEY.md §8d / BASELINE.md §2)
+FWD_GFLOP_256 = {("DU", (64, 1024)): 163.30, ("U", (64, 1024)): 101.03}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--arch", default="DU", choices=["DU", "U"])
+    ap.add_argument("--act", default="relu")
+    ap.add_argument("--norm", default="bn")
+    ap.add_argument("--filters", type=int, nargs=2, default=[64, 1024])
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "ranger"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracketing of MFMA kernels")
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, size, arch, seed, device):
+    """Synthetic crops of the training tensor contract (training_dataset.py:30-63 + mytransforms.py:380-406):
+    img fp32 in [-1,1] (1,H,W); distance labels fp32 in [0,1]; boundary labels int64 in {0,1,2}."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(batch, 1, size, size, generator=g) * 2 - 1
+    if arch == "DU":
+        l1 = torch.rand(batch, 1, size, size, generator=g)
+        l2 = torch.rand(batch, 1, size, size, generator=g)
+    else:
+        l1 = torch.randint(0, 3, (batch, size, size), generator=g)
+        l2 = None
+    return tuple(t.to(device) if t is not None else None for t in (img, l1, l2))
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(args, filters):
+    """The reference's CPU path (torch CPU fp32, all host cores) restated by oracle/unet_ref.py: same architecture,
+    loss and optimizer, batch 2, a few steps.  Baseline only — not what is shipped or measured as `value`."""
+    from oracle import unet_ref
+    from microbeseg_amd.utils.unets import build_unet
+    cores = min(host_cores(), 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    holder = build_unet(args.arch, args.act, "conv", args.norm, "cpu", 1, ch_out=3 if args.arch == "U" else 1,
+                        filters=filters)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+              else v.detach().clone()) for k, v in holder.state_dict().items()}
+    plist = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(plist, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+    b = 2
+    img, l1, l2 = synthetic_batch(b, args.size, args.arch, 99, "cpu")
+
+    def step():
+        opt.zero_grad()
+        out = unet_ref.unet_forward(sd, img, args.arch, args.act, args.norm, filters, training=True,
+                                    update_running_stats=True)
+        if args.arch == "DU":
+            loss = unet_ref.regression_loss(out[0], l1) + unet_ref.regression_loss(out[1], l2)
+        else:
+            loss = unet_ref.ce_dice(out, l1)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < 15.0 and n < 8):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(b * n / dt, 4), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{n} training steps of batch {b} ({args.size}x{args.size}) through oracle/unet_ref.py "
+                      f"(torch CPU fp32, {cores} threads), same net/loss/Adam-amsgrad"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from microbeseg_amd import engine
+    from microbeseg_amd.utils.unets import build_unet
+    from microbeseg_amd.training.losses import get_loss
+
+    filters = tuple(args.filters)
+    torch.manual_seed(0)
+    net = build_unet(args.arch, args.act, "conv", args.norm, dev, world if world > 1 else 1,
+                     ch_out=3 if args.arch == "U" else 1, filters=filters)
+    if args.optimizer == "adam":
+        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+    else:
+        from microbeseg_amd.training.ranger2020 import Ranger
+        opt = Ranger(net.parameters(), lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6)
+    crit = get_loss("smooth_l1", "distance") if args.arch == "DU" else get_loss("ce_dice", "boundary")
+    batches = [synthetic_batch(args.batch, args.size, args.arch, 1234 + 17 * rank + i, dev) for i in range(2)]
+    net.train()
+
+    def step(i):
+        img, l1, l2 = batches[i % len(batches)]
+        opt.zero_grad()
+        if args.arch == "DU":
+            border, cell = net(img)
+            loss = crit["border"](border, l1) + crit["cell"](cell, l2)
+        else:
+            loss = crit(net(img), l1)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    prof = None if args.no_kernel_timing else engine.KernelTimer()
+    engine.set_kernel_timer(prof)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    engine.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    crops = args.batch * world * args.steps
+    value = crops / dt
+    fwd_gflop = FWD_GFLOP_256.get((args.arch, filters))
+    out = {
+        "metric": "training crops/sec (256px)" if args.size == 256 else f"training crops/sec ({args.size}px)",
+        "value": round(value, 3), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.arch}-Net distance-map training step, filters "
+                               f"{list(filters)}, {args.size}x{args.size} crops, per-GPU batch {args.batch}, fp32, "
+                               f"{args.act}/{args.norm}, SmoothL1x2 + Adam(amsgrad)" if args.arch == "DU" else
+                               f"{args.arch}-Net boundary training step, filters {list(filters)}, {args.size}px, "
+                               f"batch {args.batch}, ce_dice + Adam",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+    }
+    if fwd_gflop is not None:
+        train_tflop_per_crop = 3.0 * fwd_gflop * (args.size / 256.0) ** 2 / 1e3
+        out["model_tflops_per_gpu"] = round(value / world * train_tflop_per_crop, 2)
+        out["frac_of_fp32_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_FP32_MFMA_TFLOPS, 4)
+    if prof is not None:
+        kernels = prof.summary()
+        if kernels:
+            dom = max(kernels.values(), key=lambda k: k["total_ms"])
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(dom["avg_ms"], 4), "launches": dom["launches"]}
+            out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "total_ms_per_step": round(v["total_ms"] / args.steps, 3),
+                                  "avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] // args.steps}
+                              for k, v in kernels.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, filters)
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,7 @@ typedef struct MsegWgrad {
   int32_t NB, Hp, Wp, Hq, Wq;
   int32_t KH, KW, stride, pad;
   int32_t splits; /* 0 = choose */
-  int32_t reserved;
+  int32_t phase;  /* 0 = partial + reduce, 1 = split-K partial kernel only, 2 = reduction only (profiling) */
 } MsegWgrad;
 
 size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);

@@ -42,7 +42,7 @@ class MsegWgrad(C.Structure):
                 ("nq", C.c_int32), ("Nch", C.c_int32), ("Nch_store", C.c_int32),
                 ("NB", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32), ("Hq", C.c_int32), ("Wq", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("splits", C.c_int32), ("reserved", C.c_int32)]
+                ("splits", C.c_int32), ("phase", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -85,6 +85,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the copy that is resident before this library is
+    # opened (same soname: the first one loaded wins, and a second runtime would not see torch's device/streams).
+    import torch  # noqa: F401
     path = os.environ.get("MSEG_HIP_LIB", str(LIB_PATH))
     if not os.path.exists(path):
         raise MsegLibraryError(

@@ -191,11 +191,14 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   const int T = p.KH * p.KW;
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
-  if (T == 9)
-    hipLaunchKernelGGL((wgrad_kernel<9>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
-  else
-    hipLaunchKernelGGL((wgrad_kernel<4>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
-  MSEG_LAUNCH_CHECK();
+  if (p.phase != 2) {
+    if (T == 9)
+      hipLaunchKernelGGL((wgrad_kernel<9>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<4>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
+    MSEG_LAUNCH_CHECK();
+  }
+  if (p.phase == 1) return MSEG_OK;
   const size_t total = (size_t)T * p.P.C * p.Nch;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 8192u) blocks = 8192u;

@@ -79,6 +79,42 @@ class Workspace:
         return b
 
 
+# ---- optional HIP-event timing of the MFMA kernels (bench.py roofline leg) --------------------------------------
+class KernelTimer:
+    """Brackets every launch of the matrix-core kernels with HIP events on the launch stream and keeps the
+    algorithmic FLOPs of each launch; summary() resolves the events after a synchronize."""
+
+    def __init__(self):
+        self.records = []   # (kernel name, flops, start event, end event)
+
+    def bracket(self, name, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self.records.append((name, flops, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"kernel": name, "launches": 0, "total_ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+            d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
 # ---- thin kernel wrappers ------------------------------------------------------------------------------------
 def pack_weight(src, T, R, Cc, Cpad, st, sr, sc):
     lib = _lib.load()
@@ -88,7 +124,7 @@ def pack_weight(src, T, R, Cc, Cpad, st, sr, sc):
 
 
 def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, Kpad, dst0, ld0, acc0=0,
-          dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR):
+          dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, real_cin=None):
     lib = _lib.load()
     p = MsegIgemm()
     for i, s in enumerate(srcs):
@@ -105,7 +141,16 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, K
     p.Ngemm, p.epi = Ngemm, epi
     p.split = Ngemm if split is None else split
     p.ld0, p.ld1, p.acc0, p.acc1, p.Cq = ld0, ld1, acc0, acc1, Cq
+    if _timer is None:
+        check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
+        return
+    flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
+    if mode == MODE_TCONV:
+        flops /= stride * stride
+    e0, e1 = _timer.bracket("igemm_kernel<128,128>" if Ngemm > 64 else "igemm_kernel<256,64>", flops)
+    e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
+    e1.record()
 
 
 def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None):
@@ -125,7 +170,17 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
     if need == 0:
         raise RuntimeError("libmseg_hip wgrad: unsupported shape")
     p.ws = ws.get("wgrad", need).data_ptr()
+    if _timer is None:
+        check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
+        return
+    flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
+    e0, e1 = _timer.bracket("wgrad_kernel<%d>" % (KH * KW), flops)
+    p.phase = 1     # split-K partial kernel only (timed) ...
+    e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
+    e1.record()
+    p.phase = 2     # ... then the fixed-order reduction
+    check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad_reduce")
 
 
 def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws):
@@ -263,7 +318,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
         wp = pack_weight(wt, 9, cout, cin, kp, 1, cin * 9, 9)
         Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
         z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, kp, z, cout)
+        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, kp, z, cout, real_cin=cin)
         act = spec.act
     node = Node(z, N, Ho, Wo, cout)
     node.act = act
