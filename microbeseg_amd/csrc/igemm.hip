@@ -12,8 +12,9 @@
 //
 // Tiling: a workgroup (256 threads = 4 waves) owns BM output pixels x BN output channels; every K-step stages a
 // [BM][32] slab of gathered source pixels (one tap, 32 input channels) and a [BN][32] slab of weights in LDS
-// (row stride 36 floats -> conflict-free ds_read_b128), each wave accumulates a 64x64 block as 2x2 MFMA tiles.
-// The global loads of step s+1 are issued before the MFMAs of step s (register prefetch).
+// (row stride 36 floats -> conflict-free ds_read_b128), double buffered (one barrier per K-step); each wave accumulates
+// a 64x64 (BN=128) or 32x64 (BN=64) block as 32x32 MFMA tiles.  The raw global loads of step s+1 are issued before the
+// MFMAs of step s and consumed (activation, scale/shift, ds_write) after them.
 #include "common.h"
 
 #define KC 32
@@ -77,13 +78,12 @@ __device__ __forceinline__ bool tap_coord(const MsegIgemm& p, const RowInfo& r, 
   return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool PER_SAMPLE, bool GENERIC_ACT>
 __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   using Cfg = IgemmCfg<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_STRIDE + 4];
-  float* As = lds;
-  float* Bs = lds + BM * LDS_STRIDE;
-  unsigned* tapmask_s = reinterpret_cast<unsigned*>(lds + (BM + BN) * LDS_STRIDE);
+  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + 4];
+  unsigned* tapmask_s = reinterpret_cast<unsigned*>(lds + 2 * STAGE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -136,35 +136,84 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   const int nchunks = (p.Cin + KC - 1) / KC;
   const int C0 = p.src[0].C;
 
-  float4 ra[Cfg::AROWS];
-  float4 rb[Cfg::BROWS];
+  // ---- staging registers: raw loads are issued before the MFMAs of the current step and only *used* (activation,
+  // scale/shift, LDS store) after them, so their latency hides behind the matrix work -------------------------------
+  constexpr int NSC = PER_SAMPLE ? Cfg::AROWS : 1;
+  float4 ra[Cfg::AROWS], rb[Cfg::BROWS], rsc[NSC], rsh[NSC];
+  unsigned amask = 0u;
+  int ract = 0;
 
-  auto load_step = [&](int chunk, int t) {
+  auto issue = [&](int chunk, int t) {
     const int ky = t / p.KW, kx = t - ky * p.KW;
     const int c = chunk * KC + scol * 4;
     const bool cvalid = c < p.Cin;
-    const int si = (p.nsrc > 1 && c >= C0) ? 1 : 0;
-    const MsegSrc& s = p.src[si];
-    const int cl = si ? c - C0 : c;
+    const bool s1 = (p.nsrc > 1) && (c >= C0);
+    const float* sptr = s1 ? p.src[1].ptr : p.src[0].ptr;
+    const float* sscale = s1 ? p.src[1].scale : p.src[0].scale;
+    const float* sshift = s1 ? p.src[1].shift : p.src[0].shift;
+    const int sC = s1 ? p.src[1].C : p.src[0].C;
+    const int sss = s1 ? p.src[1].ss : p.src[0].ss;
+    ract = s1 ? p.src[1].act : p.src[0].act;
+    const int cl = cvalid ? (s1 ? c - C0 : c) : 0;
+    amask = 0u;
 #pragma unroll
     for (int i = 0; i < Cfg::AROWS; ++i) {
-      int iy, ix;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cvalid && tap_coord(p, rows[i], ky, kx, iy, ix)) {
-        const size_t pix = ((size_t)rows[i].n * p.Hi + iy) * p.Wi + ix;
-        v = *reinterpret_cast<const float4*>(s.ptr + pix * s.C + cl);
-        v = src_transform4(v, s, rows[i].n, cl);
+      int iy = 0, ix = 0;
+      const bool ok = cvalid && tap_coord(p, rows[i], ky, kx, iy, ix);
+      const size_t off = ok ? (((size_t)rows[i].n * p.Hi + iy) * p.Wi + ix) * sC + cl : 0;
+      ra[i] = *reinterpret_cast<const float4*>(sptr + off);
+      amask |= ok ? (1u << i) : 0u;
+    }
+    if (sscale) {
+      if (PER_SAMPLE) {
+#pragma unroll
+        for (int i = 0; i < NSC; ++i) {
+          const int n = rows[i].n < 0 ? 0 : rows[i].n;
+          rsc[i] = *reinterpret_cast<const float4*>(sscale + (size_t)n * sss + cl);
+          rsh[i] = *reinterpret_cast<const float4*>(sshift + (size_t)n * sss + cl);
+        }
+      } else {
+        rsc[0] = *reinterpret_cast<const float4*>(sscale + cl);
+        rsh[0] = *reinterpret_cast<const float4*>(sshift + cl);
       }
-      ra[i] = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSC; ++i) {
+        rsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        rsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     const float* wt = p.w + ((size_t)t * p.Ngemm) * p.Kpad;
 #pragma unroll
     for (int i = 0; i < Cfg::BROWS; ++i) {
       const int n = n0 + srow + 32 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.Ngemm && c < p.Kpad) v = *reinterpret_cast<const float4*>(wt + (size_t)n * p.Kpad + c);
-      rb[i] = v;
+      const bool ok = (n < p.Ngemm) && (c < p.Kpad);
+      const float4 v = *reinterpret_cast<const float4*>(wt + (ok ? (size_t)n * p.Kpad + c : 0));
+      rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+
+  auto commit = [&](float* As, float* Bs) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      float4 v = ra[i];
+      if (GENERIC_ACT) {
+        v = act_fwd4(v, ract);
+      } else {
+        v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+      }
+      const float4 sc = rsc[PER_SAMPLE ? i : 0], sh = rsh[PER_SAMPLE ? i : 0];
+      const bool ok = (amask >> i) & 1u;
+      v.x = ok ? v.x * sc.x + sh.x : 0.f;
+      v.y = ok ? v.y * sc.y + sh.y : 0.f;
+      v.z = ok ? v.z * sc.z + sh.z : 0.f;
+      v.w = ok ? v.w * sc.w + sh.w : 0.f;
+      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
   };
 
   auto next_step = [&](int& chunk, int& t) -> bool {
@@ -177,21 +226,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 
   int chunk = 0, t = -1;
   bool have = (tapmask != 0u) && next_step(chunk, t);
-  if (have) load_step(chunk, t);
+  int cur = 0;
+  if (have) {
+    issue(chunk, t);
+    commit(lds, lds + BM * LDS_STRIDE);
+  }
+  __syncthreads();
 
+  const int li = lane & 31, lh = lane >> 5;
   while (have) {
-#pragma unroll
-    for (int i = 0; i < Cfg::AROWS; ++i)
-      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = ra[i];
-#pragma unroll
-    for (int i = 0; i < Cfg::BROWS; ++i)
-      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
-    __syncthreads();
+    // prefetch the next K-step (on the last step: a harmless re-read of the current one, keeps the body branch-free)
+    int nchunk = chunk, nt = t;
+    const bool have_next = next_step(nchunk, nt);
+    if (have_next) { chunk = nchunk; t = nt; }
+    issue(chunk, t);
 
-    have = next_step(chunk, t);
-    if (have) load_step(chunk, t);
-
-    const int li = lane & 31, lh = lane >> 5;
+    const float* As = lds + cur * STAGE;
+    const float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int kk = 0; kk < KC / 8; ++kk) {
       float4 af[Cfg::MB], bf[Cfg::NB];
@@ -211,11 +262,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
         }
     }
+    float* An = lds + (cur ^ 1) * STAGE;
+    commit(An, An + BM * LDS_STRIDE);
     __syncthreads();
+    cur ^= 1;
+    have = have_next;
   }
 
   // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ------------------------------------
-  const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int b = 0; b < Cfg::NB; ++b) {
     const int n = n0 + wn * Cfg::TN + b * 32 + li;
@@ -295,14 +349,26 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long M = (long long)p.NB * p.Ho * p.Wo;
   if (M <= 0 || M > 0x7fffffffLL) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (p.Ngemm > 64) {
-    const long long tiles = ((M + 127) / 128) * ((p.Ngemm + 127) / 128);
-    if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
-    hipLaunchKernelGGL((igemm_kernel<128, 128>), dim3((unsigned)tiles), dim3(256), 0, st, p);
-  } else {
-    const long long tiles = ((M + 255) / 256);
-    hipLaunchKernelGGL((igemm_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  bool per_sample = false, generic = false;
+  for (int i = 0; i < p.nsrc; ++i) {
+    if (p.src[i].scale && p.src[i].ss != 0) per_sample = true;
+    if (p.src[i].act != MSEG_ACT_NONE && p.src[i].act != MSEG_ACT_RELU) generic = true;
   }
+  const bool wide = p.Ngemm > 64;
+  const int BMv = 128, BNv = wide ? 128 : 64;
+  const long long tiles = ((M + BMv - 1) / BMv) * ((p.Ngemm + BNv - 1) / BNv);
+  if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
+  const dim3 grid((unsigned)tiles), block(256);
+#define MSEG_IGEMM_LAUNCH(BM_, BN_, PS_, GA_) \
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, PS_, GA_>), grid, block, 0, st, p)
+  if (wide) {
+    if (per_sample) { if (generic) MSEG_IGEMM_LAUNCH(128, 128, true, true); else MSEG_IGEMM_LAUNCH(128, 128, true, false); }
+    else            { if (generic) MSEG_IGEMM_LAUNCH(128, 128, false, true); else MSEG_IGEMM_LAUNCH(128, 128, false, false); }
+  } else {
+    if (per_sample) { if (generic) MSEG_IGEMM_LAUNCH(128, 64, true, true); else MSEG_IGEMM_LAUNCH(128, 64, true, false); }
+    else            { if (generic) MSEG_IGEMM_LAUNCH(128, 64, false, true); else MSEG_IGEMM_LAUNCH(128, 64, false, false); }
+  }
+#undef MSEG_IGEMM_LAUNCH
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

@@ -14,7 +14,7 @@
 #define WG_PIX 32
 #define WG_LDS 68
 
-template <int TT>
+template <int TT, bool GENERIC_ACT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int splits, int steps_per_split) {
   __shared__ __attribute__((aligned(16))) float lds[3 * WG_PIX * WG_LDS];
   float* Ps = lds;
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   const long long pix_begin = (long long)split * steps_per_split * WG_PIX;
   long long pix_end = pix_begin + (long long)steps_per_split * WG_PIX;
   if (pix_end > Ptot) pix_end = Ptot;
+  const int nsteps = pix_end > pix_begin ? (int)((pix_end - pix_begin + WG_PIX - 1) / WG_PIX) : 0;
 
   f32x16 acc[TT];
 #pragma unroll
@@ -45,75 +46,136 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   const int mc = mt * 64 + sc4 * 4;
   const int qc = nt * 64 + sc4 * 4;
   const int Q0 = p.Q[0].C;
-  const int qsi = (p.nq > 1 && qc >= Q0) ? 1 : 0;
-  const int qcl = qsi ? qc - Q0 : qc;
+  const bool q1 = (p.nq > 1) && (qc >= Q0);
   const bool mvalid = mc < Mch, qvalid = qc < Nch;
+  const int mcl = mvalid ? mc : 0;
+  const int qcl = qvalid ? (q1 ? qc - Q0 : qc) : 0;
+  const float* qptr = q1 ? p.Q[1].ptr : p.Q[0].ptr;
+  const float* qscale = q1 ? p.Q[1].scale : p.Q[0].scale;
+  const float* qshift = q1 ? p.Q[1].shift : p.Q[0].shift;
+  const int qC = q1 ? p.Q[1].C : p.Q[0].C;
+  const int qss = q1 ? p.Q[1].ss : p.Q[0].ss;
+  const int qact = q1 ? p.Q[1].act : p.Q[0].act;
+  const float qlo = (qact == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+  const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 
-  for (long long pix0 = pix_begin; pix0 < pix_end; pix0 += WG_PIX) {
-    int pn[2], py[2], px[2];
-    float4 rp[2];
+  // ---- staging registers (raw loads issued before the MFMAs of the current phase, consumed after them) ------
+  int pn[2] = {-1, -1}, py[2] = {0, 0}, px[2] = {0, 0};
+  float4 rp[2], rpsc[2], rpsh[2];
+  float4 rq[2], rqsc[2], rqsh[2];
+  unsigned pmask = 0u, qmask = 0u;
+
+  auto issue_p = [&](int step) {   // also decodes the pixel coordinates of `step`
+    const long long pix0 = pix_begin + (long long)step * WG_PIX;
+    pmask = 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long long pp = pix0 + spx + 16 * i;
-      rp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < pix_end) {
-        const int n = (int)(pp / (p.Hp * p.Wp));
-        const int rem = (int)(pp - (long long)n * (p.Hp * p.Wp));
-        pn[i] = n; py[i] = rem / p.Wp; px[i] = rem - py[i] * p.Wp;
-        if (mvalid) {
-          float4 v = *reinterpret_cast<const float4*>(p.P.ptr + (size_t)pp * Mch + mc);
-          rp[i] = src_transform4(v, p.P, n, mc);
-        }
+      const bool inr = pp < pix_end;
+      const long long ppc = inr ? pp : pix_begin;
+      const int n = (int)(ppc / (p.Hp * p.Wp));
+      const int rem = (int)(ppc - (long long)n * (p.Hp * p.Wp));
+      pn[i] = inr ? n : -1;
+      py[i] = rem / p.Wp;
+      px[i] = rem - py[i] * p.Wp;
+      const bool ok = inr && mvalid;
+      rp[i] = *reinterpret_cast<const float4*>(p.P.ptr + (ok ? (size_t)pp * Mch + mcl : 0));
+      pmask |= ok ? (1u << i) : 0u;
+      if (p.P.scale) {
+        rpsc[i] = *reinterpret_cast<const float4*>(p.P.scale + (size_t)n * p.P.ss + mcl);
+        rpsh[i] = *reinterpret_cast<const float4*>(p.P.shift + (size_t)n * p.P.ss + mcl);
       } else {
-        pn[i] = -1; py[i] = 0; px[i] = 0;
+        rpsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        rpsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  };
 
-    auto load_q = [&](int t, float4 (&rq)[2]) {
-      const int ky = t / p.KW, kx = t - ky * p.KW;
-      const MsegSrc& s = p.Q[qsi];
+  auto issue_q = [&](int t) {
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+    qmask = 0u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qvalid && pn[i] >= 0) {
-          const int qy = py[i] * p.stride + ky - p.pad, qx = px[i] * p.stride + kx - p.pad;
-          if (qy >= 0 && qy < p.Hq && qx >= 0 && qx < p.Wq) {
-            const size_t qp = ((size_t)pn[i] * p.Hq + qy) * p.Wq + qx;
-            v = *reinterpret_cast<const float4*>(s.ptr + qp * s.C + qcl);
-            v = src_transform4(v, s, pn[i], qcl);
-          }
-        }
-        rq[i] = v;
+    for (int i = 0; i < 2; ++i) {
+      const int qy = py[i] * p.stride + ky - p.pad, qx = px[i] * p.stride + kx - p.pad;
+      const bool ok = qvalid && pn[i] >= 0 && qy >= 0 && qy < p.Hq && qx >= 0 && qx < p.Wq;
+      const int n = pn[i] < 0 ? 0 : pn[i];
+      const size_t off = ok ? (((size_t)n * p.Hq + qy) * p.Wq + qx) * qC + qcl : 0;
+      rq[i] = *reinterpret_cast<const float4*>(qptr + off);
+      qmask |= ok ? (1u << i) : 0u;
+      if (qscale) {
+        rqsc[i] = *reinterpret_cast<const float4*>(qscale + (size_t)n * qss + qcl);
+        rqsh[i] = *reinterpret_cast<const float4*>(qshift + (size_t)n * qss + qcl);
+      } else {
+        rqsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        rqsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    };
+    }
+  };
 
-    float4 rq[2];
-    load_q(0, rq);
+  auto finish = [&](float4 v, float4 sc, float4 sh, bool ok, int act, float lo) -> float4 {
+    if (GENERIC_ACT) {
+      v = act_fwd4(v, act);
+    } else {
+      v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+    }
+    v.x = ok ? v.x * sc.x + sh.x : 0.f;
+    v.y = ok ? v.y * sc.y + sh.y : 0.f;
+    v.z = ok ? v.z * sc.z + sh.z : 0.f;
+    v.w = ok ? v.w * sc.w + sh.w : 0.f;
+    return v;
+  };
 
-    // previous step's readers of Ps are done (>= 1 barrier since their last read when TT >= 2)
-    if (TT < 2) __syncthreads();
+  auto commit_p = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Ps + (spx + 16 * i) * WG_LDS + sc4 * 4) = rp[i];
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(Ps + (spx + 16 * i) * WG_LDS + sc4 * 4) =
+          finish(rp[i], rpsc[i], rpsh[i], (pmask >> i) & 1u, p.P.act, plo);
+  };
+  auto commit_q = [&](float* Qb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(Qb + (spx + 16 * i) * WG_LDS + sc4 * 4) =
+          finish(rq[i], rqsc[i], rqsh[i], (qmask >> i) & 1u, qact, qlo);
+  };
 
-    float a[16];
+  // Flat sequence of phases (step, tap).  Hazards: Ps is rewritten once per step, >= TT-1 >= 3 barriers after its
+  // last reader; Qs[b] is rewritten two phases after the phase that read it (one barrier in between).
+  if (nsteps > 0) {
+    issue_p(0);
+    issue_q(0);
+    commit_p();
+    commit_q(Qs);
+  }
+  __syncthreads();
+  float a[16];
+  int buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      float* Qb = Qs + (t & 1) * WG_PIX * WG_LDS;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Qb + (spx + 16 * i) * WG_LDS + sc4 * 4) = rq[i];
-      __syncthreads();
-      if (t + 1 < TT) load_q(t + 1, rq);
+      const bool last_tap = (t == TT - 1);
+      const bool more = !(last_tap && step + 1 >= nsteps);
+      // prefetch the next phase (on the very last phase: a harmless re-read)
+      if (last_tap) {
+        if (more) issue_p(step + 1);
+        issue_q(0);
+      } else {
+        issue_q(t + 1);
+      }
       if (t == 0) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) a[kk] = Ps[(2 * kk + lh) * WG_LDS + wm * 32 + li];
       }
+      const float* Qb = Qs + buf * WG_PIX * WG_LDS;
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const float b = Qb[(2 * kk + lh) * WG_LDS + wn * 32 + li];
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[t], 0, 0, 0);
       }
+      if (last_tap && more) commit_p();
+      commit_q(Qs + (buf ^ 1) * WG_PIX * WG_LDS);
+      __syncthreads();
+      buf ^= 1;
     }
-    if (TT & 1) __syncthreads();  // odd tap count: next step's tap 0 reuses the buffer tap TT-1 just read
   }
 
   // ---- store partial tiles: ws[((split*T + t)*Mch + m)*Nch + n] ---------------------------------------------
@@ -192,10 +254,17 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   if (p.phase != 2) {
-    if (T == 9)
-      hipLaunchKernelGGL((wgrad_kernel<9>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<4>), dim3(tiles, splits), dim3(256), 0, st, p, splits, sps);
+    bool generic = (p.P.act != MSEG_ACT_NONE && p.P.act != MSEG_ACT_RELU);
+    for (int i = 0; i < p.nq; ++i)
+      if (p.Q[i].act != MSEG_ACT_NONE && p.Q[i].act != MSEG_ACT_RELU) generic = true;
+    const dim3 grid(tiles, splits), block(256);
+    if (T == 9) {
+      if (generic) hipLaunchKernelGGL((wgrad_kernel<9, true>), grid, block, 0, st, p, splits, sps);
+      else hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, block, 0, st, p, splits, sps);
+    } else {
+      if (generic) hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, block, 0, st, p, splits, sps);
+      else hipLaunchKernelGGL((wgrad_kernel<4, false>), grid, block, 0, st, p, splits, sps);
+    }
     MSEG_LAUNCH_CHECK();
   }
   if (p.phase == 1) return MSEG_OK;

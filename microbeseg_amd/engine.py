@@ -147,7 +147,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, K
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
-    e0, e1 = _timer.bracket("igemm_kernel<128,128>" if Ngemm > 64 else "igemm_kernel<256,64>", flops)
+    e0, e1 = _timer.bracket("igemm_kernel<128,128>" if Ngemm > 64 else "igemm_kernel<128,64>", flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
