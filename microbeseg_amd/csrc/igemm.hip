@@ -105,10 +105,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 #pragma unroll
   for (int i = 0; i < Cfg::AROWS; ++i) rows[i] = decode_row(p, m0 + srow + 32 * i, M);
 
-  // which taps are live for at least one row of this tile
-  if (tid == 0) *tapmask_s = 0u;
-  __syncthreads();
-  {
+  // which taps are live for at least one row of this tile: only a stride-2 transposed conv has dead taps (tile-uniform
+  // under the parity M-order); everywhere else every tap is live and per-row masks handle the borders
+  unsigned tapmask = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
+  if (p.mode == MSEG_MODE_TCONV && p.stride == 2) {
+    if (tid == 0) *tapmask_s = 0u;
+    __syncthreads();
     unsigned mine = 0u;
     for (int t = 0; t < T; ++t) {
       const int ky = t / p.KW, kx = t - ky * p.KW;
@@ -121,9 +123,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
       if (any) mine |= (1u << t);
     }
     if (mine) atomicOr(tapmask_s, mine);
+    __syncthreads();
+    tapmask = *tapmask_s;
+    __syncthreads();
   }
-  __syncthreads();
-  const unsigned tapmask = *tapmask_s;
 
   f32x16 acc[Cfg::MB][Cfg::NB];
 #pragma unroll
@@ -143,8 +146,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   unsigned amask = 0u;
   int ract = 0;
 
-  auto issue = [&](int chunk, int t) {
-    const int ky = t / p.KW, kx = t - ky * p.KW;
+  auto issue = [&](int chunk, int t, int ky, int kx) {
     const int c = chunk * KC + scol * 4;
     const bool cvalid = c < p.Cin;
     const bool s1 = (p.nsrc > 1) && (c >= C0);
@@ -216,19 +218,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
       *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
   };
 
-  auto next_step = [&](int& chunk, int& t) -> bool {
+  // K-step iterator (chunk outer, tap inner), by value so that it stays in scalar registers
+  struct Pos { int chunk, t, ky, kx; };
+  const int KWm1 = p.KW - 1;
+  auto advance = [&](Pos q, bool& ok) -> Pos {
+    ok = true;
     for (;;) {
-      ++t;
-      if (t >= T) { t = 0; ++chunk; if (chunk >= nchunks) return false; }
-      if (tapmask & (1u << t)) return true;
+      const int wrap = (q.kx == KWm1) ? 1 : 0;
+      q.t += 1;
+      q.kx = wrap ? 0 : q.kx + 1;
+      q.ky += wrap;
+      if (q.t >= T) {
+        q.t = 0; q.ky = 0; q.kx = 0; q.chunk += 1;
+        if (q.chunk >= nchunks) { ok = false; return q; }
+      }
+      if (tapmask & (1u << q.t)) return q;
     }
   };
 
-  int chunk = 0, t = -1;
-  bool have = (tapmask != 0u) && next_step(chunk, t);
+  Pos pos = {0, -1, 0, -1};
+  bool have = false;
+  if (tapmask != 0u) pos = advance(pos, have);
   int cur = 0;
   if (have) {
-    issue(chunk, t);
+    issue(pos.chunk, pos.t, pos.ky, pos.kx);
     commit(lds, lds + BM * LDS_STRIDE);
   }
   __syncthreads();
@@ -236,10 +249,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   const int li = lane & 31, lh = lane >> 5;
   while (have) {
     // prefetch the next K-step (on the last step: a harmless re-read of the current one, keeps the body branch-free)
-    int nchunk = chunk, nt = t;
-    const bool have_next = next_step(nchunk, nt);
-    if (have_next) { chunk = nchunk; t = nt; }
-    issue(chunk, t);
+    bool have_next;
+    const Pos nxt = advance(pos, have_next);
+    if (have_next) pos = nxt;
+    issue(pos.chunk, pos.t, pos.ky, pos.kx);
 
     const float* As = lds + cur * STAGE;
     const float* Bs = As + BM * LDS_STRIDE;
@@ -270,23 +283,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   }
 
   // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ------------------------------------
+  // The epilogue-only fields are re-read from kernarg memory here (opaque pointer) so that they do not occupy
+  // SGPRs during the K-loop (the whole descriptor live = SGPR spills reloaded every iteration).
+  const MsegIgemm* pe = (const MsegIgemm*)__builtin_amdgcn_kernarg_segment_ptr();  // kernel argument 0
+  asm volatile("" : "+s"(pe));
+  const float* e_bias = pe->bias;
+  float* e_dst0 = pe->dst0;
+  float* e_dst1 = pe->dst1;
+  const int e_epi = pe->epi, e_split = pe->split, e_ld0 = pe->ld0, e_ld1 = pe->ld1, e_acc0 = pe->acc0,
+            e_acc1 = pe->acc1, e_Cq = pe->Cq, e_morder = pe->morder, e_Ho = pe->Ho, e_Wo = pe->Wo, e_Ngemm = pe->Ngemm;
 #pragma unroll
   for (int b = 0; b < Cfg::NB; ++b) {
     const int n = n0 + wn * Cfg::TN + b * 32 + li;
-    const bool nvalid = n < p.Ngemm;
+    const bool nvalid = n < e_Ngemm;
     float bias = 0.f;
-    float* dst = p.dst0;
-    int ld = p.ld0, noff = n, accf = p.acc0;
+    float* dst = e_dst0;
+    int ld = e_ld0, noff = n, accf = e_acc0;
     int sa = 0, sb = 0;
-    if (p.epi == MSEG_EPI_SCATTER2X2) {
-      const int ab = nvalid ? n / p.Cq : 0;
-      const int co = n - ab * p.Cq;
+    if (e_epi == MSEG_EPI_SCATTER2X2) {
+      const int ab = nvalid ? n / e_Cq : 0;
+      const int co = n - ab * e_Cq;
       sa = ab >> 1; sb = ab & 1;
       noff = co;
-      if (p.bias && nvalid) bias = p.bias[co];
+      if (e_bias && nvalid) bias = e_bias[co];
     } else {
-      if (n >= p.split) { dst = p.dst1; ld = p.ld1; noff = n - p.split; accf = p.acc1; }
-      if (p.bias && nvalid) bias = p.bias[n];
+      if (n >= e_split) { dst = e_dst1; ld = e_ld1; noff = n - e_split; accf = e_acc1; }
+      if (e_bias && nvalid) bias = e_bias[n];
     }
 #pragma unroll
     for (int a = 0; a < Cfg::MB; ++a) {
@@ -296,14 +318,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
         const int m = m0 + wm * Cfg::TM + a * 32 + row;
         if (!nvalid || m >= M) continue;
         size_t off;
-        if (p.epi == MSEG_EPI_SCATTER2X2) {
-          const int img = m / (p.Ho * p.Wo);
-          const int rem = m - img * (p.Ho * p.Wo);
-          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-          off = (((size_t)img * (2 * p.Ho) + 2 * oy + sa) * (2 * p.Wo) + 2 * ox + sb) * p.Cq + noff;
-        } else if (p.morder == MSEG_MORDER_PARITY) {
-          const RowInfo ri = decode_row(p, m, M);
-          off = (((size_t)ri.n * p.Ho + ri.oy) * p.Wo + ri.ox) * ld + noff;
+        if (e_epi == MSEG_EPI_SCATTER2X2) {
+          const int img = m / (e_Ho * e_Wo);
+          const int rem = m - img * (e_Ho * e_Wo);
+          const int oy = rem / e_Wo, ox = rem - oy * e_Wo;
+          off = (((size_t)img * (2 * e_Ho) + 2 * oy + sa) * (2 * e_Wo) + 2 * ox + sb) * e_Cq + noff;
+        } else if (e_morder == MSEG_MORDER_PARITY) {
+          const RowInfo ri = decode_row(*pe, m, M);
+          off = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
         } else {
           off = (size_t)m * ld + noff;
         }

@@ -4,30 +4,34 @@
 //
 //   G[t][mch][nch] = sum over pixels p of  P[p][mch] * Q[gather(p, t)][nch]
 //
-// GEMM view: M = mch (64 per workgroup), N = nch (64 per workgroup), K = pixels (split across gridDim.y).
-// One workgroup keeps the accumulators of ALL taps (<= 9 x 16 registers per wave), so the P slab of a K-step
-// (32 pixels x 64 channels) is staged once and its MFMA A-fragments stay in registers across the taps; the
-// Q slab of each tap is a shifted re-read of the same neighbourhood (L2 hits).  Q is normalised on load, so the
-// normalised activation is never stored.  Partial sums go to a split-K workspace that is reduced in fixed order.
+// GEMM view: M = mch (64 per workgroup), N = nch (64 per workgroup), K = pixels (split across gridDim.y); a
+// workgroup owns one kernel row ky (gridDim.z) and keeps the accumulators of its KW taps (KW x 16 registers per
+// wave), so the P slab of a K-step (32 pixels x 64 channels) is staged once and its MFMA A-fragments are reused by
+// the KW taps; the Q slabs are x-shifted re-reads of the same neighbourhood (L2 hits).  P and Q are normalised on
+// load, so the normalised activation is never stored.  Stages are double buffered in LDS: one barrier per
+// KW x 16 MFMAs.  Partial sums go to a split-K workspace that is reduced in fixed order (deterministic).
 #include "common.h"
 
 #define WG_PIX 32
 #define WG_LDS 68
 
-template <int TT, bool GENERIC_ACT>
+// KWT = taps handled by one workgroup (= one kernel row ky = blockIdx.z): 3 for the 3x3 convs, 2 for the 2x2 convT.
+template <int KWT, bool GENERIC_ACT, bool PER_SAMPLE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int splits, int steps_per_split) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * WG_PIX * WG_LDS];
-  float* Ps = lds;
-  float* Qs = lds + WG_PIX * WG_LDS;
+  constexpr int SLAB = WG_PIX * WG_LDS;              // one [32 px][64 ch] slab (row stride 68)
+  constexpr int STAGE = (1 + KWT) * SLAB;            // P slab + KWT tap slabs
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
   const int Mch = p.P.C, Nch = p.Nch;
+  const int T = p.KH * p.KW;
   const int ntiles_n = (Nch + 63) / 64;
   const int mt = blockIdx.x / ntiles_n, nt = blockIdx.x - mt * ntiles_n;
   const int split = blockIdx.y;
+  const int ky = blockIdx.z;
 
   const long long Ptot = (long long)p.NB * p.Hp * p.Wp;
   const long long pix_begin = (long long)split * steps_per_split * WG_PIX;
@@ -35,9 +39,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   if (pix_end > Ptot) pix_end = Ptot;
   const int nsteps = pix_end > pix_begin ? (int)((pix_end - pix_begin + WG_PIX - 1) / WG_PIX) : 0;
 
-  f32x16 acc[TT];
+  f32x16 acc[KWT];
 #pragma unroll
-  for (int t = 0; t < TT; ++t)
+  for (int t = 0; t < KWT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -59,15 +63,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   const float qlo = (qact == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
   const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 
-  // ---- staging registers (raw loads issued before the MFMAs of the current phase, consumed after them) ------
-  int pn[2] = {-1, -1}, py[2] = {0, 0}, px[2] = {0, 0};
-  float4 rp[2], rpsc[2], rpsh[2];
-  float4 rq[2], rqsc[2], rqsh[2];
+  // a thread's channel quad is fixed for the whole kernel: BatchNorm-style tables (ss == 0) are loaded once
+  constexpr int NS = PER_SAMPLE ? 2 : 1;
+  const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 psc[NS], psh[NS], qsc[NS], qsh[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    psc[i] = (p.P.scale && !PER_SAMPLE) ? *reinterpret_cast<const float4*>(p.P.scale + mcl) : one4;
+    psh[i] = (p.P.scale && !PER_SAMPLE) ? *reinterpret_cast<const float4*>(p.P.shift + mcl) : zero4;
+    qsc[i] = (qscale && !PER_SAMPLE) ? *reinterpret_cast<const float4*>(qscale + qcl) : one4;
+    qsh[i] = (qscale && !PER_SAMPLE) ? *reinterpret_cast<const float4*>(qshift + qcl) : zero4;
+  }
+
+  // ---- staging registers (raw loads are issued before the MFMAs of the current step, consumed after them) ----
+  float4 rp[2], rq[KWT][2];
   unsigned pmask = 0u, qmask = 0u;
 
-  auto issue_p = [&](int step) {   // also decodes the pixel coordinates of `step`
+  auto issue = [&](int step) {
     const long long pix0 = pix_begin + (long long)step * WG_PIX;
-    pmask = 0u;
+    pmask = 0u; qmask = 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long long pp = pix0 + spx + 16 * i;
@@ -75,39 +89,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
       const long long ppc = inr ? pp : pix_begin;
       const int n = (int)(ppc / (p.Hp * p.Wp));
       const int rem = (int)(ppc - (long long)n * (p.Hp * p.Wp));
-      pn[i] = inr ? n : -1;
-      py[i] = rem / p.Wp;
-      px[i] = rem - py[i] * p.Wp;
-      const bool ok = inr && mvalid;
-      rp[i] = *reinterpret_cast<const float4*>(p.P.ptr + (ok ? (size_t)pp * Mch + mcl : 0));
-      pmask |= ok ? (1u << i) : 0u;
-      if (p.P.scale) {
-        rpsc[i] = *reinterpret_cast<const float4*>(p.P.scale + (size_t)n * p.P.ss + mcl);
-        rpsh[i] = *reinterpret_cast<const float4*>(p.P.shift + (size_t)n * p.P.ss + mcl);
-      } else {
-        rpsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        rpsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int py = rem / p.Wp;
+      const int px = rem - py * p.Wp;
+      const bool pok = inr && mvalid;
+      rp[i] = *reinterpret_cast<const float4*>(p.P.ptr + (pok ? (size_t)pp * Mch + mcl : 0));
+      pmask |= pok ? (1u << i) : 0u;
+      if (PER_SAMPLE) {
+        if (p.P.scale) {
+          psc[i] = *reinterpret_cast<const float4*>(p.P.scale + (size_t)n * p.P.ss + mcl);
+          psh[i] = *reinterpret_cast<const float4*>(p.P.shift + (size_t)n * p.P.ss + mcl);
+        }
+        if (qscale) {
+          qsc[i] = *reinterpret_cast<const float4*>(qscale + (size_t)n * qss + qcl);
+          qsh[i] = *reinterpret_cast<const float4*>(qshift + (size_t)n * qss + qcl);
+        }
       }
-    }
-  };
-
-  auto issue_q = [&](int t) {
-    const int ky = t / p.KW, kx = t - ky * p.KW;
-    qmask = 0u;
+      const int qy = py * p.stride + ky - p.pad;
+      const bool yok = qvalid && inr && qy >= 0 && qy < p.Hq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int qy = py[i] * p.stride + ky - p.pad, qx = px[i] * p.stride + kx - p.pad;
-      const bool ok = qvalid && pn[i] >= 0 && qy >= 0 && qy < p.Hq && qx >= 0 && qx < p.Wq;
-      const int n = pn[i] < 0 ? 0 : pn[i];
-      const size_t off = ok ? (((size_t)n * p.Hq + qy) * p.Wq + qx) * qC + qcl : 0;
-      rq[i] = *reinterpret_cast<const float4*>(qptr + off);
-      qmask |= ok ? (1u << i) : 0u;
-      if (qscale) {
-        rqsc[i] = *reinterpret_cast<const float4*>(qscale + (size_t)n * qss + qcl);
-        rqsh[i] = *reinterpret_cast<const float4*>(qshift + (size_t)n * qss + qcl);
-      } else {
-        rqsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        rqsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kx = 0; kx < KWT; ++kx) {
+        const int qx = px * p.stride + kx - p.pad;
+        const bool ok = yok && qx >= 0 && qx < p.Wq;
+        const size_t off = ok ? (((size_t)n * p.Hq + qy) * p.Wq + qx) * qC + qcl : 0;
+        rq[kx][i] = *reinterpret_cast<const float4*>(qptr + off);
+        qmask |= ok ? (1u << (kx * 2 + i)) : 0u;
       }
     }
   };
@@ -125,68 +130,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
     return v;
   };
 
-  auto commit_p = [&]() {
+  auto commit = [&](float* stage) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(Ps + (spx + 16 * i) * WG_LDS + sc4 * 4) =
-          finish(rp[i], rpsc[i], rpsh[i], (pmask >> i) & 1u, p.P.act, plo);
-  };
-  auto commit_q = [&](float* Qb) {
+    for (int i = 0; i < 2; ++i) {
+      const int si = PER_SAMPLE ? i : 0;
+      float* row = stage + (spx + 16 * i) * WG_LDS + sc4 * 4;
+      *reinterpret_cast<float4*>(row) = finish(rp[i], psc[si], psh[si], (pmask >> i) & 1u, p.P.act, plo);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(Qb + (spx + 16 * i) * WG_LDS + sc4 * 4) =
-          finish(rq[i], rqsc[i], rqsh[i], (qmask >> i) & 1u, qact, qlo);
+      for (int kx = 0; kx < KWT; ++kx)
+        *reinterpret_cast<float4*>(row + (1 + kx) * SLAB) =
+            finish(rq[kx][i], qsc[si], qsh[si], (qmask >> (kx * 2 + i)) & 1u, qact, qlo);
+    }
   };
 
-  // Flat sequence of phases (step, tap).  Hazards: Ps is rewritten once per step, >= TT-1 >= 3 barriers after its
-  // last reader; Qs[b] is rewritten two phases after the phase that read it (one barrier in between).
+  // double-buffered stages, one barrier per 32-pixel step (KWT x 16 MFMAs per wave)
   if (nsteps > 0) {
-    issue_p(0);
-    issue_q(0);
-    commit_p();
-    commit_q(Qs);
+    issue(0);
+    commit(lds);
   }
   __syncthreads();
-  float a[16];
   int buf = 0;
   for (int step = 0; step < nsteps; ++step) {
+    issue(step + 1 < nsteps ? step + 1 : step);   // last step: harmless re-read keeps the body branch-free
+    const float* st = lds + buf * STAGE;
+    float a[16];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      const bool last_tap = (t == TT - 1);
-      const bool more = !(last_tap && step + 1 >= nsteps);
-      // prefetch the next phase (on the very last phase: a harmless re-read)
-      if (last_tap) {
-        if (more) issue_p(step + 1);
-        issue_q(0);
-      } else {
-        issue_q(t + 1);
-      }
-      if (t == 0) {
+    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WG_LDS + wm * 32 + li];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) a[kk] = Ps[(2 * kk + lh) * WG_LDS + wm * 32 + li];
-      }
-      const float* Qb = Qs + buf * WG_PIX * WG_LDS;
+    for (int kx = 0; kx < KWT; ++kx) {
+      const float* Qb = st + (1 + kx) * SLAB;
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const float b = Qb[(2 * kk + lh) * WG_LDS + wn * 32 + li];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[t], 0, 0, 0);
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
       }
-      if (last_tap && more) commit_p();
-      commit_q(Qs + (buf ^ 1) * WG_PIX * WG_LDS);
-      __syncthreads();
-      buf ^= 1;
     }
+    commit(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
   }
 
   // ---- store partial tiles: ws[((split*T + t)*Mch + m)*Nch + n] ---------------------------------------------
   const int n = nt * 64 + wn * 32 + li;
   if (n < Nch) {
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int kx = 0; kx < KWT; ++kx) {
+      const int t = ky * KWT + kx;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < Mch) p.ws[(((size_t)split * TT + t) * Mch + m) * Nch + n] = acc[t][r];
+        if (m < Mch) p.ws[(((size_t)split * T + t) * Mch + m) * Nch + n] = acc[kx][r];
       }
     }
   }
@@ -213,7 +206,8 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   if (Ptot <= 0) return MSEG_EINVAL;
   const long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
-  long long s = p.splits > 0 ? p.splits : (1024 + tiles - 1) / tiles;
+  const int per_split_wgs = tiles * p.KH;
+  long long s = p.splits > 0 ? p.splits : (1536 + per_split_wgs - 1) / per_split_wgs;
   if (s > steps_total) s = steps_total;
   if (s > 2048) s = 2048;
   if (s < 1) s = 1;
@@ -231,8 +225,7 @@ static int wgrad_check(const MsegWgrad& p) {
     csum += p.Q[i].C;
   }
   if (csum != p.Nch || p.Nch_store <= 0 || p.Nch_store > p.Nch) return MSEG_EINVAL;
-  const int T = p.KH * p.KW;
-  if (T != 9 && T != 4) return MSEG_EINVAL;
+  if (!((p.KH == 3 && p.KW == 3) || (p.KH == 2 && p.KW == 2))) return MSEG_EINVAL;
   if (p.NB <= 0 || p.Hp <= 0 || p.Wp <= 0 || p.Hq <= 0 || p.Wq <= 0 || p.stride < 1) return MSEG_EINVAL;
   return MSEG_OK;
 }
@@ -255,16 +248,22 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (p.phase != 2) {
     bool generic = (p.P.act != MSEG_ACT_NONE && p.P.act != MSEG_ACT_RELU);
-    for (int i = 0; i < p.nq; ++i)
+    bool per_sample = (p.P.scale && p.P.ss != 0);
+    for (int i = 0; i < p.nq; ++i) {
       if (p.Q[i].act != MSEG_ACT_NONE && p.Q[i].act != MSEG_ACT_RELU) generic = true;
-    const dim3 grid(tiles, splits), block(256);
-    if (T == 9) {
-      if (generic) hipLaunchKernelGGL((wgrad_kernel<9, true>), grid, block, 0, st, p, splits, sps);
-      else hipLaunchKernelGGL((wgrad_kernel<9, false>), grid, block, 0, st, p, splits, sps);
-    } else {
-      if (generic) hipLaunchKernelGGL((wgrad_kernel<4, true>), grid, block, 0, st, p, splits, sps);
-      else hipLaunchKernelGGL((wgrad_kernel<4, false>), grid, block, 0, st, p, splits, sps);
+      if (p.Q[i].scale && p.Q[i].ss != 0) per_sample = true;
     }
+    const dim3 grid(tiles, splits, p.KH), block(256);
+#define MSEG_WGRAD_LAUNCH(KW_, GA_, PS_) \
+  hipLaunchKernelGGL((wgrad_kernel<KW_, GA_, PS_>), grid, block, 0, st, p, splits, sps)
+    if (p.KW == 3) {
+      if (generic) { if (per_sample) MSEG_WGRAD_LAUNCH(3, true, true); else MSEG_WGRAD_LAUNCH(3, true, false); }
+      else         { if (per_sample) MSEG_WGRAD_LAUNCH(3, false, true); else MSEG_WGRAD_LAUNCH(3, false, false); }
+    } else {
+      if (generic) { if (per_sample) MSEG_WGRAD_LAUNCH(2, true, true); else MSEG_WGRAD_LAUNCH(2, true, false); }
+      else         { if (per_sample) MSEG_WGRAD_LAUNCH(2, false, true); else MSEG_WGRAD_LAUNCH(2, false, false); }
+    }
+#undef MSEG_WGRAD_LAUNCH
     MSEG_LAUNCH_CHECK();
   }
   if (p.phase == 1) return MSEG_OK;

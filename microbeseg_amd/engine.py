@@ -174,7 +174,7 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
         check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
         return
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
-    e0, e1 = _timer.bracket("wgrad_kernel<%d>" % (KH * KW), flops)
+    e0, e1 = _timer.bracket("wgrad_kernel<%d>" % KW, flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
