@@ -151,8 +151,10 @@ int mseg_regression_loss_bwd(const float* pred, const float* target, size_t n, i
  * are exposed so a data-parallel caller can all-reduce them between the two calls.        */
 int mseg_ce_dice_fwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice, double* sums6,
                      double* ce_sum, void* ws, void* stream);
+/* dice_weight: 1 for single-process training; the world size under data parallelism (the Dice term is a function
+ * of GLOBAL sums, so its per-rank gradient must survive the 1/world averaging of the gradient all-reduce).   */
 int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice, const double* sums6,
-                     double total_px, const float* gscale_dev, float* grad, void* stream);
+                     double total_px, double dice_weight, const float* gscale_dev, float* grad, void* stream);
 
 /* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
 int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,

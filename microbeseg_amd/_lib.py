@@ -67,7 +67,7 @@ SIGNATURES = {
     "mseg_regression_loss": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),
     "mseg_regression_loss_bwd": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),
     "mseg_ce_dice_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, _P, _P, _P]),
+    "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, C.c_double, _P, _P, _P]),
     "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),

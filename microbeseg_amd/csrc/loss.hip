@@ -156,7 +156,7 @@ extern "C" int mseg_ce_dice_fwd(const float* logits, const int64_t* labels, int 
 // d/dlogit_k [ CE_mean + 0.5 * sum_c c * (1 - (2 I_c + 1)/(G_c + P_c + 1)) ]
 __global__ void ce_dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int N,
                                    int HW, int with_dice, const double* __restrict__ sums6, double total_px,
-                                   const float* __restrict__ gscale, float* __restrict__ grad) {
+                                   float dice_weight, const float* __restrict__ gscale, float* __restrict__ grad) {
   const float gs = gscale ? gscale[0] : 1.f;
   float A[3] = {0, 0, 0}, B[3] = {1, 1, 1};
   if (with_dice) {
@@ -180,7 +180,7 @@ __global__ void ce_dice_bwd_kernel(const float* __restrict__ logits, const int64
       // dDice_c/dp_c = -2 g_c / B_c + 2 A_c p_c / B_c^2 ;  dp_c/dlogit_k = p_c (delta_ck - p_k)
       for (int c = 1; c <= 2; ++c) {
         const float gc = (y == c) ? 1.f : 0.f;
-        const float D = 0.5f * (float)c * (-2.f * gc / B[c] + 2.f * A[c] * pr[c] / (B[c] * B[c]));
+        const float D = dice_weight * 0.5f * (float)c * (-2.f * gc / B[c] + 2.f * A[c] * pr[c] / (B[c] * B[c]));
         for (int k = 0; k < 3; ++k) g[k] += D * pr[c] * ((k == c ? 1.f : 0.f) - pr[k]);
       }
     }
@@ -190,11 +190,11 @@ __global__ void ce_dice_bwd_kernel(const float* __restrict__ logits, const int64
 }
 
 extern "C" int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice,
-                                const double* sums6, double total_px, const float* gscale_dev, float* grad,
-                                void* stream) {
+                                const double* sums6, double total_px, double dice_weight, const float* gscale_dev,
+                                float* grad, void* stream) {
   if (!logits || !labels || !sums6 || !grad || N <= 0 || HW <= 0 || total_px <= 0.0) return MSEG_EINVAL;
   hipLaunchKernelGGL(ce_dice_bwd_kernel, dim3(loss_blocks((size_t)N * HW) * 4), dim3(256), 0, (hipStream_t)stream,
-                     logits, labels, N, HW, with_dice, sums6, total_px, gscale_dev, grad);
+                     logits, labels, N, HW, with_dice, sums6, total_px, (float)dice_weight, gscale_dev, grad);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

@@ -395,7 +395,7 @@ def _accumulate_target(node, shape_like):
     return node.grad, 1
 
 
-def backward(spec, tape, grad_outs, ws):
+def backward(spec, tape, grad_outs, ws, on_grads=None):
     """grad_outs: list of NCHW gradients (None allowed) matching the forward outputs.  Returns {id(param): grad}."""
     lib = _lib.load()
     grads = {}
@@ -418,6 +418,8 @@ def backward(spec, tape, grad_outs, ws):
         node.grad = gy
         grads[id(hc.weight)] = dW
         grads[id(hc.bias)] = db
+        if on_grads is not None:
+            on_grads([dW, db])
 
     for node in reversed(tape.nodes):
         sp = node.layer
@@ -471,6 +473,8 @@ def backward(spec, tape, grad_outs, ws):
                           MODE_TCONV, cin, _pad4(cout), t0, i0.C, acc0=a0, dst1=t1, ld1=i1.C, acc1=a1,
                           split=i0.C, morder=morder)
         grads[id(conv.weight)] = dW
+        if on_grads is not None:        # data-parallel: gradients of this layer are final -> start their all-reduce
+            on_grads([dW, dbias, dgamma, dbeta])
         del dz, gy
     return grads
 
@@ -493,7 +497,12 @@ class _NetFunction(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("backward through the HIP U-Net twice is not supported")
         ctx.tape = None
-        grads = backward(module._spec, tape, list(grad_outs), module._workspace(tape.nodes[0].z.device))
+        factory = getattr(module, "_grad_sync_factory", None)
+        sync = factory() if factory is not None else None
+        grads = backward(module._spec, tape, list(grad_outs), module._workspace(tape.nodes[0].z.device),
+                         on_grads=sync.add if sync is not None else None)
+        if sync is not None:
+            sync.finish()               # averaged in place (RCCL all-reduce overlapped with the kernels above)
         plist = module._spec.params()
         return (None, None) + tuple(grads.get(id(p)) for p in plist)
 

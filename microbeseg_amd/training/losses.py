@@ -77,7 +77,7 @@ class _CeDiceFn(torch.autograd.Function):
         ws = torch.empty(lib.mseg_loss_workspace_bytes(N * H * W), dtype=torch.uint8, device=dev)
         _lib.check(lib.mseg_ce_dice_fwd(y_pred.data_ptr(), y_true.data_ptr(), N, H * W, int(with_dice),
                                         sums.data_ptr(), ce.data_ptr(), ws.data_ptr(), _stream()), "ce_dice_fwd")
-        sums, total = _allreduce_dice(sums, float(N * H * W))
+        sums, dice_weight = _allreduce_dice(sums, float(N * H * W))
         loss = ce[0] / (N * H * W)
         if with_dice:
             for c in (1, 2):
@@ -85,6 +85,7 @@ class _CeDiceFn(torch.autograd.Function):
                 loss = loss + 0.5 * c * (1.0 - (2.0 * i + 1.0) / (g + p + 1.0))
         ctx.save_for_backward(y_pred, y_true, sums)
         ctx.with_dice = int(with_dice)
+        ctx.dice_weight = dice_weight
         return loss.to(torch.float32)
 
     @staticmethod
@@ -95,15 +96,17 @@ class _CeDiceFn(torch.autograd.Function):
         g = gout.contiguous().to(torch.float32).reshape(1)
         grad = torch.empty_like(y_pred)
         _lib.check(lib.mseg_ce_dice_bwd(y_pred.data_ptr(), y_true.data_ptr(), N, H * W, ctx.with_dice,
-                                        sums.data_ptr(), float(N * H * W), g.data_ptr(), grad.data_ptr(), _stream()),
+                                        sums.data_ptr(), float(N * H * W), float(ctx.dice_weight), g.data_ptr(),
+                                        grad.data_ptr(), _stream()),
                    "ce_dice_bwd")
         return grad, None, None
 
 
 def _allreduce_dice(sums, total):
-    """Hook for data-parallel training: the reference computes the Dice sums on the gathered global batch
-    (nn.DataParallel, losses.py:65-66); microbeseg_amd.parallel installs an all-reduce here."""
-    return sums, total
+    """Data-parallel training: the reference computes the Dice sums on the gathered global batch (nn.DataParallel,
+    losses.py:65-66) -> all-reduce the six partial sums.  Returns (global sums, dice weight)."""
+    from ..parallel import allreduce_dice_sums
+    return allreduce_dice_sums(sums, total)
 
 
 def ce_dice(y_pred, y_true, num_classes=3):
