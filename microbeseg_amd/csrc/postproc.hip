@@ -1,8 +1,597 @@
-// postproc.hip — placeholder until the HIP post-processing lands (returns MSEG_EINVAL; nothing routes through it yet).
+// postproc.hip — prediction -> instance labels on the GPU, bit-exact with the reference's CPU chain
+//   distance_postprocessing  (src/inference/postprocessing.py:7-59)
+//   boundary_postprocessing  (src/inference/postprocessing.py:62-90)
+// i.e. scipy.ndimage.gaussian_filter(sigma 0.5) -> thresholds / tan -> skimage.measure.label (8-conn) -> small-seed
+// removal -> relabel -> skimage.segmentation.watershed(markers, mask) (4-conn priority flood), semantics per
+// SURVEY.md Appendix B (recovered from scipy 1.7.1 / scikit-image 0.18.3).
+//
+// HBM-bound integer/byte work — no MFMA.  Stages:
+//   gaussian (2 passes, fp64 accumulate in scipy's order, no FMA contraction) + thresholds: streaming kernels;
+//   connected components: lock-free union-find (atomicMin), root = smallest raster index of the component;
+//   ordering of instance ids: prefix sum over "first pixel" flags (raster or column-major key space);
+//   watershed: the reference is a strictly serial priority flood keyed (value, age).  Within one 4-connected
+//     component of the mask the flood is independent of all other components as long as no two *initial* marker
+//     pixels of that component carry exactly equal values (age-0 ties are broken by the global heap layout).  So:
+//     fast path = one GPU thread per mask component, each running the exact textbook heap on its own segment
+//     (64 floods per wavefront in lock step); every equal-key comparison between age-0 entries raises a taint
+//     flag, and a tainted frame (always: the constant image of the boundary method) is re-done by the exact
+//     global serial flood, on the device, without a host round trip.
 #include "common.h"
-extern "C" size_t mseg_postproc_workspace_bytes(int H, int W) { (void)H; (void)W; return 0; }
-extern "C" int mseg_distance_postprocess(const float*, const float*, int, int, float, float, int, uint16_t*, int32_t*,
-                                         int32_t*, void*, size_t, void*) { return MSEG_EINVAL; }
-extern "C" int mseg_boundary_postprocess(const float*, int, int, uint16_t*, int32_t*, int32_t*, void*, size_t, void*) {
-  return MSEG_EINVAL;
+#include <math.h>
+
+#define PP_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (PP_BLOCK * SCAN_ITEMS)
+
+// counters (int32 slots in workspace)
+enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_COUNT = 16 };
+
+struct PPWs {
+  float* tmp; float* cs;
+  uint8_t* mask; uint8_t* seedb; uint8_t* hasm;
+  int32_t* slab; int32_t* area; int32_t* ckey; int32_t* flag; int32_t* scan; int32_t* bsum;
+  int32_t* markers; int32_t* mlab; int32_t* out; int32_t* carea; int32_t* hoff; int32_t* clist;
+  int32_t* bymin; int32_t* bymax; int32_t* bxmin; int32_t* bxmax;
+  unsigned long long* hkey; uint32_t* hidx;
+  int32_t* counters;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t pp_carve(PPWs* w, void* base, int H, int W) {
+  const size_t n = (size_t)H * W;
+  const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+  size_t off = 0;
+  char* b = (char*)base;
+#define PP_TAKE(field, type, count)                         \
+  do {                                                      \
+    off = align_up(off, 256);                               \
+    if (w) w->field = (type*)(b + off);                     \
+    off += sizeof(type) * (size_t)(count);                  \
+  } while (0)
+  PP_TAKE(tmp, float, n); PP_TAKE(cs, float, n);
+  PP_TAKE(mask, uint8_t, n); PP_TAKE(seedb, uint8_t, n); PP_TAKE(hasm, uint8_t, n);
+  PP_TAKE(slab, int32_t, n); PP_TAKE(area, int32_t, n); PP_TAKE(ckey, int32_t, n); PP_TAKE(flag, int32_t, n);
+  PP_TAKE(scan, int32_t, n); PP_TAKE(bsum, int32_t, 2 * nb);
+  PP_TAKE(markers, int32_t, n); PP_TAKE(mlab, int32_t, n); PP_TAKE(out, int32_t, n); PP_TAKE(carea, int32_t, n);
+  PP_TAKE(hoff, int32_t, n); PP_TAKE(clist, int32_t, n);
+  PP_TAKE(bymin, int32_t, n); PP_TAKE(bymax, int32_t, n); PP_TAKE(bxmin, int32_t, n); PP_TAKE(bxmax, int32_t, n);
+  PP_TAKE(hkey, unsigned long long, n + 1); PP_TAKE(hidx, uint32_t, n + 1);
+  PP_TAKE(counters, int32_t, C_COUNT);
+#undef PP_TAKE
+  return align_up(off, 256);
+}
+
+extern "C" size_t mseg_postproc_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL) return 0;
+  return pp_carve(nullptr, nullptr, H, W);
+}
+
+static inline unsigned pp_blocks(size_t n) {
+  size_t b = (n + PP_BLOCK - 1) / PP_BLOCK;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---- gaussian_filter(sigma 0.5), one axis: tmp = c*w2; tmp += (m2+p2)*w0; tmp += (m1+p1)*w1 in fp64, round to fp32 ----
+__device__ __forceinline__ int pp_reflect(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return i;
+}
+
+__global__ void pp_gauss_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int axis,
+                                double w0, double w1, double w2) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  double c, m1, p1, m2, p2;
+  if (axis == 0) {
+    c = in[i];
+    m2 = in[(size_t)pp_reflect(y - 2, H) * W + x]; p2 = in[(size_t)pp_reflect(y + 2, H) * W + x];
+    m1 = in[(size_t)pp_reflect(y - 1, H) * W + x]; p1 = in[(size_t)pp_reflect(y + 1, H) * W + x];
+  } else {
+    const float* row = in + (size_t)y * W;
+    c = row[x];
+    m2 = row[pp_reflect(x - 2, W)]; p2 = row[pp_reflect(x + 2, W)];
+    m1 = row[pp_reflect(x - 1, W)]; p1 = row[pp_reflect(x + 1, W)];
+  }
+  // explicit rounding at every step (scipy's correlate1d is compiled without FMA)
+  double t = __dmul_rn(c, w2);
+  t = __dadd_rn(t, __dmul_rn(__dadd_rn(m2, p2), w0));
+  t = __dadd_rn(t, __dmul_rn(__dadd_rn(m1, p1), w1));
+  out[i] = (float)t;
+}
+
+// ---- thresholds -----------------------------------------------------------------------------------------------
+__global__ void pp_distance_thresh_kernel(const float* __restrict__ border, const float* __restrict__ cs, size_t n,
+                                          float th_cell, float th_seed, uint8_t* __restrict__ mask,
+                                          uint8_t* __restrict__ seedb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float b = border[i];
+  b = b < 0.f ? 0.f : (b > 1.f ? 1.f : b);       // np.clip(border, 0, 1)
+  const float c = cs[i];
+  mask[i] = c > th_cell;
+  const float b2 = __fmul_rn(b, b);              // border ** 2 in float32
+  float t = (float)tan((double)b2);              // np.tan(float32): evaluated in fp64, rounded once
+  if (t < 0.05f) t = 0.f;
+  t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+  seedb[i] = __fsub_rn(c, t) > th_seed;
+}
+
+__global__ void pp_boundary_thresh_kernel(const float* __restrict__ p, size_t n, uint8_t* __restrict__ mask,
+                                          uint8_t* __restrict__ seedb, float* __restrict__ img) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float p0 = p[3 * i], p1 = p[3 * i + 1], p2 = p[3 * i + 2];
+  int arg = 0;                                   // np.argmax: first maximum wins
+  float best = p0;
+  if (p1 > best) { best = p1; arg = 1; }
+  if (p2 > best) { best = p2; arg = 2; }
+  const bool m = (arg == 1);
+  mask[i] = m;
+  seedb[i] = __fmul_rn(p1, __fsub_rn(1.f, p2)) > 0.5f;
+  img[i] = m ? 1.f : 0.f;                        // watershed(image=mask): constant inside the mask
+}
+
+__global__ void pp_negate_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -in[i];
+}
+
+// ---- union-find connected components ------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int32_t* L, int i) {
+  int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (p != i) {
+    i = p;
+    p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return i;
+}
+
+__device__ __forceinline__ void uf_union(int32_t* L, int a, int b) {
+  for (;;) {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }   // a < b: hang b under a
+    const int old = atomicMin(&L[b], a);
+    if (old == b) return;
+    b = old;                                        // somebody else re-rooted b meanwhile: retry with its new parent
+  }
+}
+
+__global__ void pp_ccl_init_kernel(const uint8_t* __restrict__ bin, int32_t* __restrict__ L, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) L[i] = bin[i] ? (int32_t)i : -1;
+}
+
+template <bool EIGHT>
+__global__ void pp_ccl_merge_kernel(const uint8_t* __restrict__ bin, int32_t* __restrict__ L, int H, int W) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !bin[i]) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  if (x > 0 && bin[i - 1]) uf_union(L, (int)i, (int)i - 1);
+  if (y > 0) {
+    if (bin[i - W]) uf_union(L, (int)i, (int)i - W);
+    if (EIGHT) {
+      if (x > 0 && bin[i - W - 1]) uf_union(L, (int)i, (int)i - W - 1);
+      if (x + 1 < W && bin[i - W + 1]) uf_union(L, (int)i, (int)i - W + 1);
+    }
+  }
+}
+
+__global__ void pp_ccl_flatten_kernel(int32_t* __restrict__ L, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (L[i] >= 0) L[i] = uf_find(L, (int)i);       // roots are fixed points, so concurrent flattening is benign
+}
+
+// ---- seed statistics, filtering, ordering ----------------------------------------------------------------------------
+__global__ void pp_fill_kernel(int32_t* __restrict__ a, int32_t v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+__global__ void pp_seed_stats_kernel(const int32_t* __restrict__ L, int H, int W, int col_major,
+                                     int32_t* __restrict__ area, int32_t* __restrict__ ckey,
+                                     int32_t* __restrict__ counters) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = L[i];
+  if (r < 0) return;
+  atomicAdd(&area[r], 1);
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  atomicMin(&ckey[r], col_major ? x * H + y : (int)i);
+  atomicAdd(&counters[C_TOTAL], 1);
+  if (r == (int)i) atomicAdd(&counters[C_NCOMP], 1);
+}
+
+__device__ __forceinline__ bool pp_keep(int area, const int32_t* counters, int distance_rule) {
+  double min_area = 4.0;                                      // boundary: area <= 4 removed
+  if (distance_rule) {
+    const int nc = counters[C_NCOMP];
+    double m = nc > 0 ? 0.10 * ((double)counters[C_TOTAL] / (double)nc) : 0.0;   // 0.10 * np.mean(areas)
+    min_area = m > 4.0 ? m : 4.0;                             // np.maximum(min_area, 4)
+  }
+  return !((double)area <= min_area);
+}
+
+__global__ void pp_seed_select_kernel(const int32_t* __restrict__ L, size_t n, const int32_t* __restrict__ area,
+                                      const int32_t* __restrict__ ckey, int distance_rule,
+                                      int32_t* __restrict__ flag, int32_t* __restrict__ counters) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || L[i] != (int)i) return;
+  if (pp_keep(area[i], counters, distance_rule)) {
+    flag[ckey[i]] = 1;
+    atomicAdd(&counters[C_KEPT], 1);
+  }
+}
+
+__global__ void pp_markers_kernel(const int32_t* __restrict__ L, size_t n, const int32_t* __restrict__ area,
+                                  const int32_t* __restrict__ ckey, const int32_t* __restrict__ scan,
+                                  const uint8_t* __restrict__ mask, int distance_rule,
+                                  const int32_t* __restrict__ counters, int32_t* __restrict__ markers,
+                                  int32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int id = 0;
+  const int r = L[i];
+  if (r >= 0 && mask[i] && pp_keep(area[r], counters, distance_rule)) id = scan[ckey[r]] + 1;   // markers * mask
+  markers[i] = id;
+  out[i] = id;
+}
+
+// ---- exclusive prefix sum (3 kernels) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(PP_BLOCK) void pp_scan_tile_kernel(const int32_t* __restrict__ in,
+                                                                int32_t* __restrict__ out,
+                                                                int32_t* __restrict__ bsum, size_t n) {
+  __shared__ int32_t sh[PP_BLOCK];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < PP_BLOCK; o <<= 1) {
+    const int32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int32_t run = sh[threadIdx.x] - s;   // exclusive offset of this thread within the tile
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == PP_BLOCK - 1) bsum[blockIdx.x] = sh[PP_BLOCK - 1];
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void pp_scan_sums_kernel(int32_t* __restrict__ bsum, int nb,
+                                                                int32_t* __restrict__ total) {
+  __shared__ int32_t sh[PP_BLOCK];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += PP_BLOCK) {
+    const int i = base + threadIdx.x;
+    const int32_t v = i < nb ? bsum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < PP_BLOCK; o <<= 1) {
+      const int32_t t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) bsum[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sh[PP_BLOCK - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ void pp_scan_add_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ bsum, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += bsum[i / SCAN_TILE];
+}
+
+static int pp_exclusive_scan(const int32_t* in, int32_t* out, int32_t* bsum, size_t n, int32_t* total_dev,
+                             hipStream_t st) {
+  const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(pp_scan_tile_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, in, out, bsum, n);
+  hipLaunchKernelGGL(pp_scan_sums_kernel, dim3(1), dim3(PP_BLOCK), 0, st, bsum, nb, total_dev);
+  hipLaunchKernelGGL(pp_scan_add_kernel, dim3(pp_blocks(n)), dim3(PP_BLOCK), 0, st, out, (const int32_t*)bsum, n);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- watershed ----------------------------------------------------------------------------------------------------------
+// heap element = 64-bit key (order-preserving float bits << 32 | age) + pixel index; smaller key pops first.
+__device__ __forceinline__ unsigned long long pp_key(float v, unsigned age) {
+  if (v == 0.f) v = 0.f;                               // -0.0 == +0.0 for the reference's float compare
+  unsigned u = __float_as_uint(v);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;          // monotone map float -> uint
+  return ((unsigned long long)u << 32) | age;
+}
+
+struct PPHeap {
+  unsigned long long* key;
+  uint32_t* idx;
+  int n;
+  int taint;
+};
+
+__device__ __forceinline__ bool pp_less(PPHeap& h, unsigned long long a, unsigned long long b) {
+  (void)h;
+  return a < b;
+}
+
+__device__ __forceinline__ void pp_push(PPHeap& h, unsigned long long k, uint32_t ix) {
+  int child = h.n++;
+  h.key[child] = k; h.idx[child] = ix;
+  while (child > 0) {
+    const int parent = (child + 1) / 2 - 1;
+    const unsigned long long kp = h.key[parent];
+    if (pp_less(h, k, kp)) {
+      h.key[child] = kp; h.idx[child] = h.idx[parent];
+      h.key[parent] = k; h.idx[parent] = ix;
+      child = parent;
+    } else break;
+  }
+}
+
+__device__ __forceinline__ void pp_pop(PPHeap& h, unsigned long long& tk, uint32_t& ti) {
+  tk = h.key[0]; ti = h.idx[0];
+  const int n = --h.n;
+  if (n == 0) return;
+  const unsigned long long lk = h.key[n];
+  const uint32_t li = h.idx[n];
+  h.key[0] = lk; h.idx[0] = li;
+  int i = 0;
+  for (;;) {
+    const int l = 2 * i + 1, r = 2 * i + 2;
+    if (l >= n) break;
+    int smallest = i;
+    unsigned long long ks = lk;                       // key currently at position i is always `last`
+    const unsigned long long kl = h.key[l];
+    if (pp_less(h, kl, ks)) { smallest = l; ks = kl; }
+    if (r < n) {
+      const unsigned long long kr = h.key[r];
+      if (pp_less(h, kr, ks)) { smallest = r; ks = kr; }
+    }
+    if (smallest == i) break;
+    h.key[i] = ks; h.idx[i] = h.idx[smallest];
+    h.key[smallest] = lk; h.idx[smallest] = li;
+    i = smallest;
+  }
+}
+
+// flood from a filled heap; `age` continues the caller's counter
+__device__ __forceinline__ void pp_flood(PPHeap& h, const float* __restrict__ img, const uint8_t* __restrict__ mask,
+                                         int32_t* __restrict__ out, int H, int W, unsigned age) {
+  // Keys are unique except between initial (age 0) markers of equal value; such a pair is ordered by the layout of
+  // the reference's single global heap, which a per-component heap cannot know.  Equal keys pop consecutively
+  // (sorted order), so one comparison with the previous key detects every such pair -> taint -> exact serial redo.
+  unsigned long long prev = ~0ull;
+  while (h.n > 0) {
+    unsigned long long k; uint32_t e;
+    pp_pop(h, k, e);
+    if (k == prev) h.taint = 1;
+    prev = k;
+    const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+    const int lab = out[e];
+    // neighbour order of skimage's raveled offsets: up, left, right, down
+    if (y > 0)     { const uint32_t j = e - W; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
+    if (x > 0)     { const uint32_t j = e - 1; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
+    if (x + 1 < W) { const uint32_t j = e + 1; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
+    if (y + 1 < H) { const uint32_t j = e + W; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
+  }
+}
+
+// mask-component statistics: pixel count, bounding box, "has a marker"
+__global__ void pp_mcomp_stats_kernel(const int32_t* __restrict__ mlab, const int32_t* __restrict__ markers, int H,
+                                      int W, int32_t* __restrict__ carea, int32_t* __restrict__ bymin,
+                                      int32_t* __restrict__ bymax, int32_t* __restrict__ bxmin,
+                                      int32_t* __restrict__ bxmax, uint8_t* __restrict__ hasm) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = mlab[i];
+  if (r < 0) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  atomicAdd(&carea[r], 1);
+  atomicMin(&bymin[r], y); atomicMax(&bymax[r], y);
+  atomicMin(&bxmin[r], x); atomicMax(&bxmax[r], x);
+  if (markers[i] != 0) hasm[r] = 1;
+}
+
+// flag = 1 at roots of components that contain a marker; carea zeroed elsewhere (it becomes the heap-size scan input)
+__global__ void pp_mcomp_flag_kernel(const int32_t* __restrict__ mlab, const uint8_t* __restrict__ hasm, size_t n,
+                                     int32_t* __restrict__ flag, int32_t* __restrict__ carea) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool on = (mlab[i] == (int)i) && hasm[i];
+  flag[i] = on ? 1 : 0;
+  if (!on) carea[i] = 0;
+}
+
+__global__ void pp_mcomp_list_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, size_t n,
+                                     int32_t* __restrict__ clist) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) clist[scan[i]] = (int32_t)i;
+}
+
+// fast path: one thread per mask component (64 independent exact floods per wavefront)
+__global__ __launch_bounds__(64) void pp_flood_components_kernel(
+    const float* __restrict__ img, const uint8_t* __restrict__ mask, const int32_t* __restrict__ markers,
+    const int32_t* __restrict__ mlab, const int32_t* __restrict__ clist, const int32_t* __restrict__ hoff,
+    const int32_t* __restrict__ bymin, const int32_t* __restrict__ bymax, const int32_t* __restrict__ bxmin,
+    const int32_t* __restrict__ bxmax, unsigned long long* __restrict__ hkey, uint32_t* __restrict__ hidx,
+    int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+  if (counters[C_SERIAL]) return;                        // caller forces the exact serial path (boundary method)
+  const int ncomp = counters[C_NMCOMP];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncomp; c += gridDim.x * blockDim.x) {
+    const int root = clist[c];
+    PPHeap h;
+    h.key = hkey + hoff[root];
+    h.idx = hidx + hoff[root];
+    h.n = 0; h.taint = 0;
+    // initial heap: marker pixels of this component in ascending raster index, all with age 0
+    const int y0 = bymin[root], y1 = bymax[root], x0 = bxmin[root], x1 = bxmax[root];
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x) {
+        const uint32_t j = (uint32_t)y * W + x;
+        if (mlab[j] == root && markers[j] != 0) pp_push(h, pp_key(img[j], 0u), j);
+      }
+    pp_flood(h, img, mask, out, H, W, 0u);
+    if (h.taint) counters[C_TAINT] = 1;
+  }
+}
+
+// exact path: the whole image through ONE heap, exactly like the reference (single thread; correctness anchor)
+__global__ void pp_flood_serial_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask,
+                                       const int32_t* __restrict__ markers, unsigned long long* __restrict__ hkey,
+                                       uint32_t* __restrict__ hidx, int32_t* __restrict__ out, int H, int W,
+                                       int32_t* __restrict__ counters) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (!counters[C_SERIAL] && !counters[C_TAINT]) return;
+  const size_t n = (size_t)H * W;
+  for (size_t i = 0; i < n; ++i) out[i] = markers[i];    // discard whatever the fast path wrote
+  PPHeap h;
+  h.key = hkey; h.idx = hidx; h.n = 0; h.taint = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (markers[i] != 0) pp_push(h, pp_key(img[i], 0u), (uint32_t)i);
+  pp_flood(h, img, mask, out, H, W, 0u);
+  counters[C_SCRATCH] = 1;                               // status bit 0: exact serial path was used
+}
+
+__global__ void pp_finalize_kernel(const int32_t* __restrict__ out, uint16_t* __restrict__ labels, size_t n,
+                                   const int32_t* __restrict__ counters, int32_t* __restrict__ n_inst,
+                                   int32_t* __restrict__ status) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) labels[i] = (uint16_t)out[i];               // astype(np.uint16): wraps above 65535 like the reference
+  if (i == 0) {
+    if (n_inst) *n_inst = counters[C_KEPT];
+    if (status) *status = (counters[C_SCRATCH] ? 1 : 0) | (counters[C_TAINT] ? 2 : 0);
+  }
+}
+
+static void pp_gauss_weights(double w[3]) {
+  // scipy.ndimage._gaussian_kernel1d(sigma=0.5, order=0, radius=2): exp(-0.5/sigma^2 * x^2) / sum, float64 (host libm)
+  const double sigma2 = 0.5 * 0.5;
+  double phi[5], sum = 0.0;
+  for (int i = 0; i < 5; ++i) {
+    const double x = (double)(i - 2);
+    phi[i] = exp(-0.5 / sigma2 * x * x);
+    sum += phi[i];
+  }
+  w[0] = phi[0] / sum; w[1] = phi[1] / sum; w[2] = phi[2] / sum;
+}
+
+// shared tail: seeds (binary) + mask + image -> labels
+static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int distance_rule, int col_major,
+                              int force_serial, uint16_t* labels, int32_t* n_inst, int32_t* status, hipStream_t st) {
+  const size_t n = (size_t)H * W;
+  const unsigned nb = pp_blocks(n);
+  (void)hipMemsetAsync(w.counters, 0, sizeof(int32_t) * C_COUNT, st);
+  if (force_serial) hipLaunchKernelGGL(pp_fill_kernel, dim3(1), dim3(PP_BLOCK), 0, st, w.counters + C_SERIAL, 1, (size_t)1);
+  (void)hipMemsetAsync(w.area, 0, sizeof(int32_t) * n, st);
+  (void)hipMemsetAsync(w.flag, 0, sizeof(int32_t) * n, st);
+  hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.ckey, 0x7fffffff, n);
+  // 8-connected seed components
+  hipLaunchKernelGGL(pp_ccl_init_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const uint8_t*)w.seedb, w.slab, n);
+  hipLaunchKernelGGL((pp_ccl_merge_kernel<true>), dim3(nb), dim3(PP_BLOCK), 0, st, (const uint8_t*)w.seedb, w.slab, H, W);
+  hipLaunchKernelGGL(pp_ccl_flatten_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.slab, n);
+  hipLaunchKernelGGL(pp_seed_stats_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.slab, H, W, col_major,
+                     w.area, w.ckey, w.counters);
+  hipLaunchKernelGGL(pp_seed_select_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.slab, n,
+                     (const int32_t*)w.area, (const int32_t*)w.ckey, distance_rule, w.flag, w.counters);
+  MSEG_LAUNCH_CHECK();
+  if (pp_exclusive_scan(w.flag, w.scan, w.bsum, n, nullptr, st)) return MSEG_ELAUNCH;
+  hipLaunchKernelGGL(pp_markers_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.slab, n,
+                     (const int32_t*)w.area, (const int32_t*)w.ckey, (const int32_t*)w.scan, (const uint8_t*)w.mask,
+                     distance_rule, (const int32_t*)w.counters, w.markers, w.out);
+  // 4-connected mask components -> independent floods
+  hipLaunchKernelGGL(pp_ccl_init_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const uint8_t*)w.mask, w.mlab, n);
+  hipLaunchKernelGGL((pp_ccl_merge_kernel<false>), dim3(nb), dim3(PP_BLOCK), 0, st, (const uint8_t*)w.mask, w.mlab, H, W);
+  hipLaunchKernelGGL(pp_ccl_flatten_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.mlab, n);
+  (void)hipMemsetAsync(w.carea, 0, sizeof(int32_t) * n, st);
+  (void)hipMemsetAsync(w.hasm, 0, n, st);
+  (void)hipMemsetAsync(w.bymax, 0, sizeof(int32_t) * n, st);
+  (void)hipMemsetAsync(w.bxmax, 0, sizeof(int32_t) * n, st);
+  hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.bymin, 0x7fffffff, n);
+  hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.bxmin, 0x7fffffff, n);
+  hipLaunchKernelGGL(pp_mcomp_stats_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.mlab,
+                     (const int32_t*)w.markers, H, W, w.carea, w.bymin, w.bymax, w.bxmin, w.bxmax, w.hasm);
+  hipLaunchKernelGGL(pp_mcomp_flag_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.mlab,
+                     (const uint8_t*)w.hasm, n, w.flag, w.carea);
+  MSEG_LAUNCH_CHECK();
+  if (pp_exclusive_scan(w.carea, w.hoff, w.bsum, n, nullptr, st)) return MSEG_ELAUNCH;             // heap segments
+  if (pp_exclusive_scan(w.flag, w.scan, w.bsum, n, w.counters + C_NMCOMP, st)) return MSEG_ELAUNCH; // compact list
+  hipLaunchKernelGGL(pp_mcomp_list_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.flag,
+                     (const int32_t*)w.scan, n, w.clist);
+  hipLaunchKernelGGL(pp_flood_components_kernel, dim3(1024), dim3(64), 0, st, img, (const uint8_t*)w.mask,
+                     (const int32_t*)w.markers, (const int32_t*)w.mlab, (const int32_t*)w.clist,
+                     (const int32_t*)w.hoff, (const int32_t*)w.bymin, (const int32_t*)w.bymax,
+                     (const int32_t*)w.bxmin, (const int32_t*)w.bxmax, w.hkey, w.hidx, w.out, H, W, w.counters);
+  hipLaunchKernelGGL(pp_flood_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask,
+                     (const int32_t*)w.markers, w.hkey, w.hidx, w.out, H, W, w.counters);
+  hipLaunchKernelGGL(pp_finalize_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.out, labels, n,
+                     (const int32_t*)w.counters, n_inst, status);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_distance_postprocess(const float* border, const float* cell, int H, int W, float th_cell,
+                                         float th_seed, int col_major_ids, uint16_t* labels, int32_t* n_instances_dev,
+                                         int32_t* status_dev, void* ws, size_t ws_bytes, void* stream) {
+  if (!border || !cell || !labels || !ws || H <= 0 || W <= 0) return MSEG_EINVAL;
+  const size_t need = mseg_postproc_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PPWs w;
+  pp_carve(&w, ws, H, W);
+  const size_t n = (size_t)H * W;
+  const unsigned nb = pp_blocks(n);
+  double gw[3];
+  pp_gauss_weights(gw);
+  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, cell, w.tmp, H, W, 0, gw[0], gw[1], gw[2]);
+  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.tmp, w.cs, H, W, 1, gw[0], gw[1], gw[2]);
+  hipLaunchKernelGGL(pp_distance_thresh_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, border, (const float*)w.cs, n,
+                     th_cell, th_seed, w.mask, w.seedb);
+  hipLaunchKernelGGL(pp_negate_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.cs, w.tmp, n);  // image = -cell
+  MSEG_LAUNCH_CHECK();
+  return pp_seeds_to_labels(w, w.tmp, H, W, 1, col_major_ids, 0, labels, n_instances_dev, status_dev, st);
+}
+
+extern "C" int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, uint16_t* labels,
+                                         int32_t* n_instances_dev, int32_t* status_dev, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  if (!probs_hwc || !labels || !ws || H <= 0 || W <= 0) return MSEG_EINVAL;
+  const size_t need = mseg_postproc_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PPWs w;
+  pp_carve(&w, ws, H, W);
+  const size_t n = (size_t)H * W;
+  hipLaunchKernelGGL(pp_boundary_thresh_kernel, dim3(pp_blocks(n)), dim3(PP_BLOCK), 0, st, probs_hwc, n, w.mask,
+                     w.seedb, w.tmp);
+  MSEG_LAUNCH_CHECK();
+  // constant image: every key ties -> the order is the global heap's; go straight to the exact serial flood
+  return pp_seeds_to_labels(w, w.tmp, H, W, 0, 0, 1, labels, n_instances_dev, status_dev, st);
 }
