@@ -138,6 +138,10 @@ size_t mseg_head_bwd_workspace_bytes(int N, int HW, int C, int Co);
 int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw, float* gy,
                   float* dW, float* db, void* ws, void* stream);
 
+/* softmax over the 3 boundary classes of logits [3][Hp][Wp] -> probabilities [Hp-pad_y][Wp-pad_x][3] (HWC), top/left
+ * padding cropped: F.softmax(dim=1) + slice + transpose in front of boundary_postprocessing (infer.py:371-374). */
+int mseg_softmax3_hwc(const float* logits_chw, int Hp, int Wp, int pad_y, int pad_x, float* probs_hwc, void* stream);
+
 /* ---- losses (src/training/losses.py) -----------------------------------------------------------------------
  * smooth-L1 (beta 1, mean) / L1 / MSE of one head, forward value and gradient in one pass (losses.py:24-32).
  * kind: 0 smooth_l1, 1 l1, 2 l2.  loss_out[0] = mean loss; grad = d(loss)/d(pred) * gscale_dev[0] (or 1).    */

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mseg_head_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _P, _I, _P, _P]),
     "mseg_head_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "mseg_head_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "mseg_softmax3_hwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mseg_loss_workspace_bytes": (_SZ, [_SZ]),
     "mseg_regression_loss": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),
     "mseg_regression_loss_bwd": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),

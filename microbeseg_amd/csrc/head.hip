@@ -200,3 +200,33 @@ extern "C" int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, 
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
+
+// ---- softmax over the 3 boundary classes, NCHW logits -> HWC probabilities with the top/left pad cropped ------------
+// Replaces F.softmax(prediction, dim=1)[:, :, pads[0]:, pads[1]:] + transpose to (H, W, 3) (infer.py:371-374,
+// infer_script_local.py:155-157) in front of boundary_postprocessing.
+__global__ void softmax3_hwc_kernel(const float* __restrict__ logits, int Hp, int Wp, int py, int px, int H, int W,
+                                    float* __restrict__ probs) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  const size_t src = (size_t)(y + py) * Wp + (x + px);
+  const size_t plane = (size_t)Hp * Wp;
+  const float l0 = logits[src], l1 = logits[plane + src], l2 = logits[2 * plane + src];
+  const float m = fmaxf(l0, fmaxf(l1, l2));
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+  const float s = e0 + e1 + e2;
+  probs[3 * i] = e0 / s; probs[3 * i + 1] = e1 / s; probs[3 * i + 2] = e2 / s;
+}
+
+extern "C" int mseg_softmax3_hwc(const float* logits_chw, int Hp, int Wp, int pad_y, int pad_x, float* probs_hwc,
+                                 void* stream) {
+  if (!logits_chw || !probs_hwc || Hp <= 0 || Wp <= 0 || pad_y < 0 || pad_x < 0 || pad_y >= Hp || pad_x >= Wp)
+    return MSEG_EINVAL;
+  const int H = Hp - pad_y, W = Wp - pad_x;
+  const size_t n = (size_t)H * W;
+  hipLaunchKernelGGL(softmax3_hwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     logits_chw, Hp, Wp, pad_y, pad_x, H, W, probs_hwc);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -1,0 +1,133 @@
+"""Inference driver of the hot path: per frame normalise -> U-Net forward (eval) -> un-pad -> post-processing.
+
+Mirror of ``InferWorker`` in ``src/inference/infer.py`` (reference: constructor :30-111, ``start_inference`` :113-326,
+``inference`` :328-376) and of the frame loop of ``infer_script_local.py`` (:118-161).  The OMERO plumbing of
+``start_inference`` (login, plane download, ROI upload) is outside the hot path; what is
+kept is the per-frame contract — ``inference(img, min_val, max_val, pads)`` with an already padded frame, returning the
+``np.uint16`` instance mask of the un-padded frame — plus ``infer_stack`` for local [T, H, W] stacks.
+On the MI355X path the frame stays in HBM between the network and the watershed; only the uint16 mask returns.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils.qt_shim import QObject, pyqtSignal, pyqtSlot
+from ..utils.unets import build_unet, get_weights
+from ..utils.utils import zero_pad_model_input
+from . import postprocessing as pp
+
+
+def load_model(model, device):
+    """``model``: path of the checkpoint without/with suffix; reads ``<model>.json`` (architecture, label_type) and
+    ``<model>.pth`` (state dict), like infer.py:83-84,119-131.  Returns (net in eval mode, model_settings)."""
+    model = Path(model)
+    base = model.parent / model.stem
+    if not base.with_suffix('.pth').is_file():
+        raise Exception(f'{base.with_suffix(".pth")} not found!')
+    if not base.with_suffix('.json').is_file():
+        raise Exception(f'{base.with_suffix(".json")} not found!')
+    with open(base.with_suffix('.json')) as f:
+        settings = json.load(f)
+    arch = settings['architecture']
+    net = build_unet(unet_type=arch[0], act_fun=arch[2], pool_method=arch[1], normalization=arch[3], device=device,
+                     num_gpus=1, ch_in=1, ch_out=1 if settings['label_type'] == 'distance' else 3, filters=arch[4])
+    net = get_weights(net=net, weights=str(base.with_suffix('.pth')), num_gpus=1, device=device)
+    net.eval()
+    return net, settings
+
+
+class InferWorker(QObject):
+    """ Worker class for inference """
+    finished = pyqtSignal()
+    progress = pyqtSignal(int)
+    text_output = pyqtSignal(str)
+    stop_inference = False
+
+    def __init__(self, img_id_list=None, inference_path=None, user=None, pw=None, host=None, port=None, group_id=None,
+                 model=None, device='cuda:0', ths=(0.10, 0.45), channel=0, upload=True, overwrite=True,
+                 sliding_window=False, print_output=False):
+        super().__init__()
+        self.img_id_list = img_id_list
+        self.inference_path = inference_path
+        self.omero = dict(user=user, pw=pw, host=host, port=port, group_id=group_id)
+        self.model = model
+        self.device = torch.device(device)
+        self.ths = list(ths)           # [th_cell, th_seed] (infer.py:362-365)
+        self.channel = channel
+        self.upload = upload
+        self.overwrite = overwrite
+        self.sliding_window = sliding_window   # stored, never read — exactly like the reference (infer.py:60,76)
+        self.print_output = print_output
+        self.net, self.model_settings = (None, None)
+        if model is not None:
+            self.net, self.model_settings = load_model(model, self.device)
+
+    def start_inference(self):
+        """The reference pulls planes from an OMERO server here (infer.py:113-326): not part of this build."""
+        raise RuntimeError("InferWorker.start_inference needs the OMERO stack (omero-py), which is outside the "
+                           "MI355X hot path; use infer_stack()/inference() or infer_script_local.py")
+
+    def inference(self, img, min_val, max_val, pads):
+        """ Predict one (already padded) frame.
+
+        :param img: padded frame (2-D numpy array, any integer/float dtype).
+        :param min_val: minimum of the un-padded frame (numpy scalar of the image dtype).
+        :param max_val: maximum of the un-padded frame.
+        :param pads: [rows padded at the top, columns padded at the left] (removed after the forward pass).
+        :return: instance mask, np.uint16, shape of the un-padded frame.
+        """
+        self.net.eval()
+        torch.set_grad_enabled(False)
+        # 2 * (f32(img) - min) / (max - min) - 1, same operation order and scalar types as infer.py:346-348
+        img_batch = 2 * (img.astype(np.float32) - min_val) / (max_val - min_val) - 1
+        img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
+        img_batch = img_batch.to(self.device)
+        try:
+            return self._predict(img_batch, pads)
+        except RuntimeError:   # load-bearing in the reference: zero mask instead of a crash (infer.py:354-356)
+            self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
+            return np.zeros_like(img, dtype=np.uint16)[pads[0]:, pads[1]:]
+
+    def _predict(self, img_batch, pads):
+        lib = _lib.load()
+        if self.model_settings['label_type'] == 'distance':
+            border, cell = self.net(img_batch)
+            cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
+            border = border[0, 0, pads[0]:, pads[1]:].contiguous()
+            # every reference caller hands (H, W, 1) arrays to distance_postprocessing -> column-major instance ids
+            labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1], th_cell=self.ths[0],
+                                                             col_major_ids=True)
+        else:
+            logits = self.net(img_batch).contiguous()
+            _, _, hp, wp = logits.shape
+            probs = torch.empty((hp - pads[0], wp - pads[1], 3), dtype=torch.float32, device=logits.device)
+            _lib.check(lib.mseg_softmax3_hwc(logits.data_ptr(), hp, wp, int(pads[0]), int(pads[1]), probs.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "softmax3_hwc")
+            labels, _, _ = pp.boundary_postprocessing_device(probs)
+        return labels.cpu().numpy().view(np.uint16)
+
+    def infer_stack(self, img):
+        """[T, H, W] stack -> [T, H, W] uint16 masks; per frame min/max + top/left padding exactly like
+        infer_script_local.py:118-161 / infer.py:250-259."""
+        results = np.zeros(shape=(img.shape[0], img.shape[1], img.shape[2]), dtype=np.uint16)
+        for frame in range(len(img)):
+            if self.stop_inference:
+                break
+            img_frame = np.copy(img[frame])
+            frame_min, frame_max = np.min(img_frame), np.max(img_frame)
+            img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
+            results[frame] = self.inference(img_frame, frame_min, frame_max, pads)
+            self.progress.emit(int(100 * (frame + 1) / len(img)))
+        return results
+
+    @pyqtSlot()
+    def inference_finished(self):
+        self.finished.emit()
+
+    @pyqtSlot()
+    def stop_inference_process(self):
+        """ Set internal stop state to True """
+        self.stop_inference = True

@@ -26,6 +26,15 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
 class GradBucketer:
     """Collects gradient tensors as the backward pass produces them, all-reduces them in flat buckets
     asynchronously (RCCL stream), and averages them in place at ``finish()``.  Backend agnostic (gloo in tests)."""

@@ -1,0 +1,1 @@
+from microbeseg_amd.training.train import TrainWorker, get_max_epochs, seed_worker  # noqa: F401
