@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "ranger"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracketing of MFMA kernels")
+    ap.add_argument("--no-inference", action="store_true", help="skip the secondary inference (Mpixels/s) measurement")
+    ap.add_argument("--infer-size", type=int, default=2048)
+    ap.add_argument("--infer-frames", type=int, default=3)
     return ap.parse_args()
 
 
@@ -108,6 +111,49 @@ def cpu_baseline(args, filters):
     return {"value": round(b * n / dt, 4), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": f"{n} training steps of batch {b} ({args.size}x{args.size}) through oracle/unet_ref.py "
                       f"(torch CPU fp32, {cores} threads), same net/loss/Adam-amsgrad"}
+
+
+def inference_metric(args, net, dev):
+    """Secondary metric of BASELINE.json: inference Mpixels/s including the watershed, 1 GPU, configs[4] shape
+    (2048x2048 frames, DU-Net [64,1024], batch 1).  Random weights give meaningless seeds, so the
+    network forward is timed on the frame and the post-processing on synthetic prediction maps (~2500 cells/frame)
+    that stay in HBM; Mpx/s = pixels / (t_net + t_postproc).  CPU side: the C oracle of the post-processing,
+    single thread like scipy/scikit-image, on the same maps."""
+    import numpy as np
+    from microbeseg_amd.inference import postprocessing as pp
+    from microbeseg_amd.utils import synth
+    from oracle import postproc_ref
+    S, T = args.infer_size, args.infer_frames
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2))
+    c, b = torch.from_numpy(cell).to(dev), torch.from_numpy(border).to(dev)
+    frame = (torch.rand(1, 1, S, S, device=dev) * 2 - 1)
+    net.eval()
+    with torch.no_grad():
+        net(frame)
+        pp.distance_postprocessing_device(b, c, 0.45, 0.10)
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        for _ in range(T):
+            net(frame)
+        e[1].record()
+        for _ in range(T):
+            labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
+        e[2].record()
+        torch.cuda.synchronize()
+    net.train()
+    t_net, t_pp = e[0].elapsed_time(e[1]) / T, e[1].elapsed_time(e[2]) / T
+    t0 = time.perf_counter()
+    want = postproc_ref.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
+    t_cpu = time.perf_counter() - t0
+    exact = bool(np.array_equal(labels.cpu().numpy().view(np.uint16), want))
+    return {"metric": "inference Mpixels/sec incl. watershed", "value": round(S * S / (t_net + t_pp) / 1e3, 2),
+            "unit": "Mpx/s", "frame": f"{S}x{S}", "frames": T, "net_ms": round(t_net, 2), "postproc_ms": round(t_pp, 2),
+            "postproc_Mpx_s": round(S * S / t_pp / 1e3, 1), "instances": int(n_inst), "postproc_status": int(status),
+            "labels_bit_exact_vs_oracle": exact,
+            "cpu_postproc": {"value": round(S * S / t_cpu / 1e6, 2), "unit": "Mpx/s", "cores": 1, "kind": "port",
+                             "sample": "1 frame through oracle/postproc_ref.c (single thread, like scipy/skimage)"}}
 
 
 def main():
@@ -204,6 +250,12 @@ def main():
             out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "total_ms_per_step": round(v["total_ms"] / args.steps, 3),
                                   "avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] // args.steps}
                               for k, v in kernels.items()}
+    if rank == 0 and world == 1 and not args.no_inference and args.arch == "DU":
+        del opt
+        for p_ in net.parameters():
+            p_.grad = None
+        torch.cuda.empty_cache()
+        out["inference"] = inference_metric(args, net, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, filters)
     if world > 1:

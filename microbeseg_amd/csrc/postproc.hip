@@ -13,9 +13,9 @@
 //     component of the mask the flood is independent of all other components as long as no two *initial* marker
 //     pixels of that component carry exactly equal values (age-0 ties are broken by the global heap layout).  So:
 //     fast path = one GPU thread per mask component, each running the exact textbook heap on its own segment
-//     (64 floods per wavefront in lock step); every equal-key comparison between age-0 entries raises a taint
-//     flag, and a tainted frame (always: the constant image of the boundary method) is re-done by the exact
-//     global serial flood, on the device, without a host round trip.
+//     (64 floods per wavefront in lock step); the (rare) constellations in which such a tie can change a label
+//     raise a taint flag (rules at pp_flood), and a tainted frame (always: the constant image of the boundary
+//     method) is re-done by the exact global serial flood, on the device, without a host round trip.
 #include "common.h"
 #include <math.h>
 
@@ -379,25 +379,107 @@ __device__ __forceinline__ void pp_pop(PPHeap& h, unsigned long long& tk, uint32
   }
 }
 
-// flood from a filled heap; `age` continues the caller's counter
+// Flood from a filled heap.
+//
+// TRACK = true (per-component fast path) watches for the only situations in which the result can depend on how the
+// reference's single global heap orders two *initial* markers X, Y of equal value v in one component (all other keys
+// are unique: every later push gets a fresh age).  Popped here in the order X, Y; the reference may use Y, X.
+// What the swap changes: (a) who claims a pixel adjacent to both; (b) who claims the pixels of X's / Y's *cascade*
+// (pixels with value < v that pop before the other marker); (c) the relative AGES of {pushes of X and its cascade}
+// versus {pushes of Y and its cascade} — which decides a later pop order only between entries of equal VALUE.
+// (a), (b) can change a label only if X and Y carry different labels.  Conservative rules:
+//   1   different labels, Y meets a neighbour that X has just labelled                           -> taint
+//   2a  different labels, something popped between X and Y (X's cascade)                          -> taint
+//   2b  different labels, a pop with value < v after Y (Y's cascade)                              -> taint
+//   3a  no cascade: a direct push of X and a direct push of Y have equal values                  -> taint (diff. labels)
+//                                                                                                   / sticky (same label)
+//   3b  same label with a cascade on either side, or a chain of >= 3 tied markers                -> sticky
+//   3   sticky set: two consecutive pops with equal value anywhere later in this component       -> taint
+// A taint sends the whole frame to the exact serial flood.  Tie-free float data never taints; the randomised
+// tie-stress test checks frames that contain ties and stay on this path against the oracle.
+template <bool TRACK>
 __device__ __forceinline__ void pp_flood(PPHeap& h, const float* __restrict__ img, const uint8_t* __restrict__ mask,
                                          int32_t* __restrict__ out, int H, int W, unsigned age) {
-  // Keys are unique except between initial (age 0) markers of equal value; such a pair is ordered by the layout of
-  // the reference's single global heap, which a per-component heap cannot know.  Equal keys pop consecutively
-  // (sorted order), so one comparison with the previous key detects every such pair -> taint -> exact serial redo.
-  unsigned long long prev = ~0ull;
+  unsigned long long prev0_key = ~0ull;   // last popped initial marker
+  int prev0_label = 0;
+  int since_prev0 = 0;                    // pops since that marker
+  bool prev0_tied = false;                // that marker was itself the second of a tie
+  uint32_t pushed_prev[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  unsigned pushed_prev_val[4] = {0u, 0u, 0u, 0u};
+  bool sticky = false;
+  unsigned prev_val = 0xffffffffu;        // value bits of the previous pop
+  unsigned watch_val = 0u;                // value of the last marker tie (0 = none) ...
+  bool watch_diff = false;                // ... and whether its labels differed
   while (h.n > 0) {
     unsigned long long k; uint32_t e;
     pp_pop(h, k, e);
-    if (k == prev) h.taint = 1;
-    prev = k;
     const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
     const int lab = out[e];
+    bool tie = false, tie_diff = false, had_cascade = false;
+    uint32_t pushed_now[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    unsigned pushed_now_val[4] = {0u, 0u, 0u, 0u};
+    if (TRACK) {
+      const unsigned val = (unsigned)(k >> 32), a = (unsigned)k;
+      if (sticky && val == prev_val) h.taint |= 16;                              // rule 3
+      if (watch_val && val < watch_val) {                                        // Y's cascade
+        if (watch_diff) h.taint |= 4;                                            // rule 2b
+        else sticky = true;                                                      // rule 3b
+      }
+      if (a == 0u) {
+        if (k == prev0_key) {
+          tie = true;
+          tie_diff = (lab != prev0_label);
+          if (prev0_tied) sticky = true;                                         // rule 3b (chain of ties)
+          had_cascade = since_prev0 > 0;
+          if (since_prev0 > 0) {
+            if (tie_diff) h.taint |= 2;                                          // rule 2a
+            else sticky = true;                                                  // rule 3b
+          }
+          watch_val = val; watch_diff = tie_diff;
+        } else {
+          watch_val = 0u;
+        }
+        prev0_tied = tie;
+        prev0_key = k; prev0_label = lab; since_prev0 = 0;
+      } else {
+        ++since_prev0;
+      }
+      prev_val = val;
+    }
     // neighbour order of skimage's raveled offsets: up, left, right, down
-    if (y > 0)     { const uint32_t j = e - W; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
-    if (x > 0)     { const uint32_t j = e - 1; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
-    if (x + 1 < W) { const uint32_t j = e + 1; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
-    if (y + 1 < H) { const uint32_t j = e + W; if (mask[j] && out[j] == 0) { out[j] = lab; pp_push(h, pp_key(img[j], ++age), j); } }
+#define PP_VISIT(COND, J, SLOT)                                                              \
+    if (COND) {                                                                              \
+      const uint32_t j = (J);                                                                \
+      if (mask[j]) {                                                                         \
+        if (out[j] == 0) {                                                                   \
+          const unsigned long long nk = pp_key(img[j], ++age);                               \
+          out[j] = lab; pp_push(h, nk, j);                                                   \
+          if (TRACK) { pushed_now[SLOT] = j; pushed_now_val[SLOT] = (unsigned)(nk >> 32); }  \
+        } else if (TRACK && tie_diff &&                                                      \
+                   (j == pushed_prev[0] || j == pushed_prev[1] || j == pushed_prev[2] || j == pushed_prev[3])) { \
+          h.taint |= 1;                                                     /* rule 1 */     \
+        }                                                                                    \
+      }                                                                                      \
+    }
+    PP_VISIT(y > 0, e - W, 0)
+    PP_VISIT(x > 0, e - 1, 1)
+    PP_VISIT(x + 1 < W, e + 1, 2)
+    PP_VISIT(y + 1 < H, e + W, 3)
+#undef PP_VISIT
+    if (TRACK && (unsigned)k == 0u) {
+      if (tie && !had_cascade) {                                                 // rule 3a
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (pushed_now[p] != 0xffffffffu && pushed_prev[q] != 0xffffffffu &&
+                pushed_now_val[p] == pushed_prev_val[q]) {
+              if (tie_diff) h.taint |= 8; else sticky = true;
+            }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pushed_prev[q] = pushed_now[q]; pushed_prev_val[q] = pushed_now_val[q]; }
+    }
   }
 }
 
@@ -456,8 +538,8 @@ __global__ __launch_bounds__(64) void pp_flood_components_kernel(
         const uint32_t j = (uint32_t)y * W + x;
         if (mlab[j] == root && markers[j] != 0) pp_push(h, pp_key(img[j], 0u), j);
       }
-    pp_flood(h, img, mask, out, H, W, 0u);
-    if (h.taint) counters[C_TAINT] = 1;
+    pp_flood<true>(h, img, mask, out, H, W, 0u);
+    if (h.taint) atomicOr(&counters[C_TAINT], h.taint);
   }
 }
 
@@ -474,7 +556,7 @@ __global__ void pp_flood_serial_kernel(const float* __restrict__ img, const uint
   h.key = hkey; h.idx = hidx; h.n = 0; h.taint = 0;
   for (size_t i = 0; i < n; ++i)
     if (markers[i] != 0) pp_push(h, pp_key(img[i], 0u), (uint32_t)i);
-  pp_flood(h, img, mask, out, H, W, 0u);
+  pp_flood<false>(h, img, mask, out, H, W, 0u);
   counters[C_SCRATCH] = 1;                               // status bit 0: exact serial path was used
 }
 
@@ -485,7 +567,8 @@ __global__ void pp_finalize_kernel(const int32_t* __restrict__ out, uint16_t* __
   if (i < n) labels[i] = (uint16_t)out[i];               // astype(np.uint16): wraps above 65535 like the reference
   if (i == 0) {
     if (n_inst) *n_inst = counters[C_KEPT];
-    if (status) *status = (counters[C_SCRATCH] ? 1 : 0) | (counters[C_TAINT] ? 2 : 0);
+    // bit0: exact serial flood used, bit1: tie taint, bits 8..12: which tie rule(s) fired (1, 2a, 2b, 3a, 3)
+    if (status) *status = (counters[C_SCRATCH] ? 1 : 0) | (counters[C_TAINT] ? 2 : 0) | (counters[C_TAINT] << 8);
   }
 }
 

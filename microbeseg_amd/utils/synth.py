@@ -73,3 +73,28 @@ def write_training_set(root, n_train, n_val, size=256, seed=1234, label_types=("
             if "boundary" in label_types:
                 tiffio.imwrite(d / f"boundary_{i:03d}.tif", c["boundary"])
     return root
+
+
+def synth_prediction_maps(rng, H, W, n_cells, rmin=8.0, rmax=20.0, noise=0.01):
+    """Network-output-like (cell, border) fp32 maps for post-processing benchmarks/tests: cell = per-cell radial
+    distance profile in [0,1] (max over cells), border = high where two cells overlap or touch; Gaussian noise makes
+    values tie-free like real predictions.  Bounding-box based, so 2048x2048 / 2500 cells takes ~1 s."""
+    cell = np.zeros((H, W), np.float32)
+    border = np.zeros((H, W), np.float32)
+    for _ in range(n_cells):
+        cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+        a, b, th = rng.uniform(rmin, rmax), rng.uniform(rmin, rmax), rng.uniform(0, np.pi)
+        r = int(np.ceil(max(a, b))) + 1
+        y0, y1, x0, x1 = max(0, int(cy) - r), min(H, int(cy) + r + 1), max(0, int(cx) - r), min(W, int(cx) + r + 1)
+        if y1 <= y0 or x1 <= x0:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+        u = (yy - cy) * np.cos(th) + (xx - cx) * np.sin(th)
+        v = -(yy - cy) * np.sin(th) + (xx - cx) * np.cos(th)
+        blob = np.clip(1.0 - np.sqrt((u / a) ** 2 + (v / b) ** 2), 0, 1).astype(np.float32)
+        sub = cell[y0:y1, x0:x1]
+        border[y0:y1, x0:x1] = np.maximum(border[y0:y1, x0:x1], np.minimum(sub, blob) * 3.0)
+        cell[y0:y1, x0:x1] = np.maximum(sub, blob)
+    cell += rng.normal(0, noise, cell.shape).astype(np.float32)
+    border = np.clip(border + rng.normal(0, noise, cell.shape).astype(np.float32), 0, 1).astype(np.float32)
+    return cell, border

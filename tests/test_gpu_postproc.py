@@ -98,3 +98,32 @@ def test_empty_and_full_frames(pp):
     one = np.ones((64, 96), np.float32)
     out = pp.distance_postprocessing(z[..., None], one[..., None], th_seed=0.45, th_cell=0.10)
     assert (out == 1).all()          # one seed covering everything -> a single instance
+
+
+@pytest.mark.parametrize("levels", [1 << 14, 1 << 11, 1 << 8, 1 << 5])
+def test_tie_stress_fast_path_stays_exact(levels, pp):
+    """Randomised frames whose values are quantised so that equal-valued initial markers DO occur inside components.
+    Whatever path the device takes (parallel per-component floods when the tie rules prove them safe, exact serial
+    redo otherwise) the labels must equal the oracle's; with light quantisation most frames must stay parallel —
+    i.e. the tie rules are exercised on frames that really contain ties."""
+    from oracle import postproc_ref as R
+    from microbeseg_amd.utils import synth
+    parallel_frames = tied_parallel = 0
+    n_frames = 24
+    for s in range(n_frames):
+        rng = np.random.Generator(np.random.PCG64(1000 * levels + s))
+        H, W = int(rng.integers(90, 150)), int(rng.integers(90, 150))
+        cell, border = synth.synth_prediction_maps(rng, H, W, int(rng.integers(15, 45)), rmin=5, rmax=12)
+        cell = (np.round(cell * levels) / levels).astype(np.float32)
+        c, b = torch.from_numpy(cell).cuda(), torch.from_numpy(border).cuda()
+        labels, _, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10, col_major_ids=True)
+        want = R.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
+        got = labels.cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, want), f"levels {levels} frame {s}: {(got != want).sum()} px differ, status {int(status)}"
+        if int(status) & 1 == 0:
+            parallel_frames += 1
+            seeds = cell[(cell > 0.45)]
+            tied_parallel += int(len(np.unique(seeds)) < len(seeds))
+    if levels >= (1 << 11):
+        assert parallel_frames >= n_frames // 2, f"only {parallel_frames}/{n_frames} frames stayed on the parallel path"
+        assert tied_parallel > 0, "no frame with tied seed values went through the parallel path"

@@ -1,0 +1,27 @@
+"""GPU box: HIP post-processing vs the C oracle (single thread) on synthetic 2048x2048 prediction maps."""
+import sys, pathlib, time
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+import numpy as np, torch
+from microbeseg_amd.utils import synth
+from microbeseg_amd.inference import postprocessing as pp
+from oracle import postproc_ref as R
+
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+n_cells = int(sys.argv[2]) if len(sys.argv) > 2 else int(2500 * (H * W) / 2048 ** 2)
+rng = np.random.Generator(np.random.PCG64(2024))
+t0 = time.time(); cell, border = synth.synth_prediction_maps(rng, H, W, n_cells); print("synth %.1fs" % (time.time() - t0))
+c, b = torch.from_numpy(cell).cuda(), torch.from_numpy(border).cuda()
+labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 5
+e0.record()
+for _ in range(reps):
+    labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"HIP  {ms:.2f} ms/frame  {H*W/ms/1e3:.1f} Mpx/s  instances {int(n_inst)} status {int(status)} fg {float((labels!=0).float().mean()):.3f}")
+t0 = time.time(); want = R.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10); dt = time.time() - t0
+print(f"CPU oracle (1 thread) {dt*1e3:.0f} ms/frame  {H*W/dt/1e6:.2f} Mpx/s")
+got = labels.cpu().numpy().view(np.uint16)
+print("bit-exact:", bool(np.array_equal(got, want)), "mismatch px", int((got != want).sum()))
