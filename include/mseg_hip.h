@@ -73,11 +73,11 @@ typedef struct MsegSrc {
 
 typedef struct MsegIgemm {
   MsegSrc src[2];
-  const float* w;    /* packed [T][Ngemm][Kpad], Kpad % 4 == 0, zero padded beyond Cin */
+  const float* w;    /* packed [T][Npad][Kpad], Npad % 128 == 0, Kpad % 32 == 0, zero filled beyond Ngemm / Cin */
   const float* bias; /* [Ngemm] (PLAIN) / [Cq] (SCATTER2X2) or NULL */
   float* dst0;
   float* dst1;
-  int32_t nsrc, Cin, Kpad;
+  int32_t nsrc, Cin, Kpad, Npad;
   int32_t NB, Hi, Wi, Ho, Wo;
   int32_t KH, KW, stride, pad, mode, morder;
   int32_t Ngemm, epi, split, ld0, ld1, acc0, acc1, Cq;
@@ -105,9 +105,10 @@ typedef struct MsegWgrad {
 size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);
 int mseg_wgrad(const MsegWgrad* p, void* stream);
 
-/* strided repack of a weight tensor into the [T][R][Cpad] GEMM operand:
- *   dst[(t*R + r)*Cpad + c] = c < C ? src[t*st + r*sr + c*sc] : 0                                          */
-int mseg_pack_weight(const float* src, float* dst, int T, int R, int C, int Cpad, int st, int sr, int sc, void* stream);
+/* strided repack of a weight tensor into the zero-padded [T][Rpad][Cpad] GEMM operand:
+ *   dst[(t*Rpad + r)*Cpad + c] = (r < R && c < C) ? src[t*st + r*sr + c*sc] : 0                             */
+int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C, int Cpad, int st, int sr, int sc,
+                     void* stream);
 
 /* ---- normalisation (BatchNorm2d / GroupNorm(8) / InstanceNorm2d applied AFTER the activation) --------------
  * forward statistics of a = act(z) over an NHWC tensor, fp64 accumulation:

@@ -29,7 +29,7 @@ class MsegSrc(C.Structure):
 class MsegIgemm(C.Structure):
     _fields_ = [("src", MsegSrc * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("dst0", C.c_void_p),
                 ("dst1", C.c_void_p),
-                ("nsrc", C.c_int32), ("Cin", C.c_int32), ("Kpad", C.c_int32),
+                ("nsrc", C.c_int32), ("Cin", C.c_int32), ("Kpad", C.c_int32), ("Npad", C.c_int32),
                 ("NB", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("mode", C.c_int32), ("morder", C.c_int32),
@@ -55,7 +55,7 @@ SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
-    "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),

@@ -80,6 +80,11 @@ __device__ __forceinline__ float4 src_transform4(float4 v, const MsegSrc& s, int
   return v;
 }
 
+// max(v, lo) as ONE VALU instruction (v_med3_f32); fmaxf lowers to canonicalize + v_max.  lo = 0 -> ReLU, -FLT_MAX -> no-op
+__device__ __forceinline__ float clamp_lo(float v, float lo) {
+  return __builtin_amdgcn_fmed3f(v, lo, __builtin_inff());
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -19,6 +19,17 @@
 
 #define KC 32
 #define LDS_STRIDE 36
+#define MSEG_MAX_CH 8192
+
+// identity affine for operands that carry no scale/shift table: lets the K-loop load the tables unconditionally
+__device__ float g_ident_scale[MSEG_MAX_CH];
+__device__ float g_ident_shift[MSEG_MAX_CH];
+__global__ void init_ident_kernel() {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MSEG_MAX_CH; i += gridDim.x * blockDim.x) {
+    g_ident_scale[i] = 1.f;
+    g_ident_shift[i] = 0.f;
+  }
+}
 
 template <int BM, int BN>
 struct IgemmCfg {
@@ -59,230 +70,35 @@ __device__ __forceinline__ RowInfo decode_row(const MsegIgemm& p, int m, int M) 
   return r;
 }
 
-// source pixel of (row, tap); returns false if the tap falls outside / on a dead phase
-__device__ __forceinline__ bool tap_coord(const MsegIgemm& p, const RowInfo& r, int ky, int kx, int& iy, int& ix) {
-  if (r.n < 0) return false;
-  if (p.mode == MSEG_MODE_CONV) {
-    iy = r.oy * p.stride + ky - p.pad;
-    ix = r.ox * p.stride + kx - p.pad;
-  } else {
-    const int ty = r.oy + p.pad - ky, tx = r.ox + p.pad - kx;
-    if (ty < 0 || tx < 0) return false;
-    if (p.stride == 2) {
-      if ((ty | tx) & 1) return false;
-      iy = ty >> 1; ix = tx >> 1;
-    } else {
-      iy = ty; ix = tx;
-    }
-  }
-  return iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+// Tap geometry folded into three kernel-uniform integers so that the per-row code of the K-loop is straight-line:
+//   t = o * sm + dir * (k - pad);  live iff (t & sh) == 0;  source coordinate = t >> sh
+//   CONV : sm = stride, dir = +1, sh = 0          TCONV (transposed conv / dgrad): sm = 1, dir = -1, sh = stride >> 1
+struct TapGeom { int sm, dir, sh, pad, Hi, Wi; };
+
+__device__ __forceinline__ TapGeom make_geom(const MsegIgemm& p) {
+  TapGeom g;
+  const bool conv = p.mode == MSEG_MODE_CONV;
+  g.sm = conv ? p.stride : 1;
+  g.dir = conv ? 1 : -1;
+  g.sh = conv ? 0 : (p.stride >> 1);
+  g.pad = p.pad; g.Hi = p.Hi; g.Wi = p.Wi;
+  return g;
 }
 
-template <int BM, int BN, bool PER_SAMPLE, bool GENERIC_ACT>
-__global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
+// source pixel of (row, tap); false if the tap falls outside the source / on a dead phase (no early exits)
+__device__ __forceinline__ bool tap_coord(const TapGeom& g, const RowInfo& r, int ky, int kx, int& iy, int& ix) {
+  const int ty = r.oy * g.sm + g.dir * (ky - g.pad);
+  const int tx = r.ox * g.sm + g.dir * (kx - g.pad);
+  iy = ty >> g.sh; ix = tx >> g.sh;                     // arithmetic shift: negative stays negative -> rejected below
+  return (r.n >= 0) & (((ty | tx) & g.sh) == 0) & (iy >= 0) & (iy < g.Hi) & (ix >= 0) & (ix < g.Wi);
+}
+
+// ---- shared epilogue ---------------------------------------------------------------------------------------------
+template <int BM, int BN, typename AccT>
+__device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, int m0, int n0, int wm, int wn,
+                                               int lane, int M) {
   using Cfg = IgemmCfg<BM, BN>;
-  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + 4];
-  unsigned* tapmask_s = reinterpret_cast<unsigned*>(lds + 2 * STAGE);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-
-  const int M = p.NB * p.Ho * p.Wo;
-  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
-  // consecutive workgroups share the A slab (same M tile, different N tile) -> L2 reuse
-  const int tile_m = blockIdx.x / ntiles_n;
-  const int tile_n = blockIdx.x - tile_m * ntiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int T = p.KH * p.KW;
-  const int srow = tid >> 3;  // staging row within a 32-row pass
-  const int scol = tid & 7;   // float4 column (4 channels)
-
-  RowInfo rows[Cfg::AROWS];
-#pragma unroll
-  for (int i = 0; i < Cfg::AROWS; ++i) rows[i] = decode_row(p, m0 + srow + 32 * i, M);
-
-  // which taps are live for at least one row of this tile: only a stride-2 transposed conv has dead taps (tile-uniform
-  // under the parity M-order); everywhere else every tap is live and per-row masks handle the borders
-  unsigned tapmask = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
-  if (p.mode == MSEG_MODE_TCONV && p.stride == 2) {
-    if (tid == 0) *tapmask_s = 0u;
-    __syncthreads();
-    unsigned mine = 0u;
-    for (int t = 0; t < T; ++t) {
-      const int ky = t / p.KW, kx = t - ky * p.KW;
-      bool any = false;
-#pragma unroll
-      for (int i = 0; i < Cfg::AROWS; ++i) {
-        int iy, ix;
-        any |= tap_coord(p, rows[i], ky, kx, iy, ix);
-      }
-      if (any) mine |= (1u << t);
-    }
-    if (mine) atomicOr(tapmask_s, mine);
-    __syncthreads();
-    tapmask = *tapmask_s;
-    __syncthreads();
-  }
-
-  f32x16 acc[Cfg::MB][Cfg::NB];
-#pragma unroll
-  for (int a = 0; a < Cfg::MB; ++a)
-#pragma unroll
-    for (int b = 0; b < Cfg::NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int nchunks = (p.Cin + KC - 1) / KC;
-  const int C0 = p.src[0].C;
-
-  // ---- staging registers: raw loads are issued before the MFMAs of the current step and only *used* (activation,
-  // scale/shift, LDS store) after them, so their latency hides behind the matrix work -------------------------------
-  constexpr int NSC = PER_SAMPLE ? Cfg::AROWS : 1;
-  float4 ra[Cfg::AROWS], rb[Cfg::BROWS], rsc[NSC], rsh[NSC];
-  unsigned amask = 0u;
-  int ract = 0;
-
-  auto issue = [&](int chunk, int t, int ky, int kx) {
-    const int c = chunk * KC + scol * 4;
-    const bool cvalid = c < p.Cin;
-    const bool s1 = (p.nsrc > 1) && (c >= C0);
-    const float* sptr = s1 ? p.src[1].ptr : p.src[0].ptr;
-    const float* sscale = s1 ? p.src[1].scale : p.src[0].scale;
-    const float* sshift = s1 ? p.src[1].shift : p.src[0].shift;
-    const int sC = s1 ? p.src[1].C : p.src[0].C;
-    const int sss = s1 ? p.src[1].ss : p.src[0].ss;
-    ract = s1 ? p.src[1].act : p.src[0].act;
-    const int cl = cvalid ? (s1 ? c - C0 : c) : 0;
-    amask = 0u;
-#pragma unroll
-    for (int i = 0; i < Cfg::AROWS; ++i) {
-      int iy = 0, ix = 0;
-      const bool ok = cvalid && tap_coord(p, rows[i], ky, kx, iy, ix);
-      const size_t off = ok ? (((size_t)rows[i].n * p.Hi + iy) * p.Wi + ix) * sC + cl : 0;
-      ra[i] = *reinterpret_cast<const float4*>(sptr + off);
-      amask |= ok ? (1u << i) : 0u;
-    }
-    if (sscale) {
-      if (PER_SAMPLE) {
-#pragma unroll
-        for (int i = 0; i < NSC; ++i) {
-          const int n = rows[i].n < 0 ? 0 : rows[i].n;
-          rsc[i] = *reinterpret_cast<const float4*>(sscale + (size_t)n * sss + cl);
-          rsh[i] = *reinterpret_cast<const float4*>(sshift + (size_t)n * sss + cl);
-        }
-      } else {
-        rsc[0] = *reinterpret_cast<const float4*>(sscale + cl);
-        rsh[0] = *reinterpret_cast<const float4*>(sshift + cl);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NSC; ++i) {
-        rsc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        rsh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    const float* wt = p.w + ((size_t)t * p.Ngemm) * p.Kpad;
-#pragma unroll
-    for (int i = 0; i < Cfg::BROWS; ++i) {
-      const int n = n0 + srow + 32 * i;
-      const bool ok = (n < p.Ngemm) && (c < p.Kpad);
-      const float4 v = *reinterpret_cast<const float4*>(wt + (ok ? (size_t)n * p.Kpad + c : 0));
-      rb[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-
-  auto commit = [&](float* As, float* Bs) {
-    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
-#pragma unroll
-    for (int i = 0; i < Cfg::AROWS; ++i) {
-      float4 v = ra[i];
-      if (GENERIC_ACT) {
-        v = act_fwd4(v, ract);
-      } else {
-        v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
-      }
-      const float4 sc = rsc[PER_SAMPLE ? i : 0], sh = rsh[PER_SAMPLE ? i : 0];
-      const bool ok = (amask >> i) & 1u;
-      v.x = ok ? v.x * sc.x + sh.x : 0.f;
-      v.y = ok ? v.y * sc.y + sh.y : 0.f;
-      v.z = ok ? v.z * sc.z + sh.z : 0.f;
-      v.w = ok ? v.w * sc.w + sh.w : 0.f;
-      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < Cfg::BROWS; ++i)
-      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
-  };
-
-  // K-step iterator (chunk outer, tap inner), by value so that it stays in scalar registers
-  struct Pos { int chunk, t, ky, kx; };
-  const int KWm1 = p.KW - 1;
-  auto advance = [&](Pos q, bool& ok) -> Pos {
-    ok = true;
-    for (;;) {
-      const int wrap = (q.kx == KWm1) ? 1 : 0;
-      q.t += 1;
-      q.kx = wrap ? 0 : q.kx + 1;
-      q.ky += wrap;
-      if (q.t >= T) {
-        q.t = 0; q.ky = 0; q.kx = 0; q.chunk += 1;
-        if (q.chunk >= nchunks) { ok = false; return q; }
-      }
-      if (tapmask & (1u << q.t)) return q;
-    }
-  };
-
-  Pos pos = {0, -1, 0, -1};
-  bool have = false;
-  if (tapmask != 0u) pos = advance(pos, have);
-  int cur = 0;
-  if (have) {
-    issue(pos.chunk, pos.t, pos.ky, pos.kx);
-    commit(lds, lds + BM * LDS_STRIDE);
-  }
-  __syncthreads();
-
   const int li = lane & 31, lh = lane >> 5;
-  while (have) {
-    // prefetch the next K-step (on the last step: a harmless re-read of the current one, keeps the body branch-free)
-    bool have_next;
-    const Pos nxt = advance(pos, have_next);
-    if (have_next) pos = nxt;
-    issue(pos.chunk, pos.t, pos.ky, pos.kx);
-
-    const float* As = lds + cur * STAGE;
-    const float* Bs = As + BM * LDS_STRIDE;
-#pragma unroll
-    for (int kk = 0; kk < KC / 8; ++kk) {
-      float4 af[Cfg::MB], bf[Cfg::NB];
-#pragma unroll
-      for (int a = 0; a < Cfg::MB; ++a)
-        af[a] = *reinterpret_cast<const float4*>(As + (wm * Cfg::TM + a * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
-#pragma unroll
-      for (int b = 0; b < Cfg::NB; ++b)
-        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn * Cfg::TN + b * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
-#pragma unroll
-      for (int a = 0; a < Cfg::MB; ++a)
-#pragma unroll
-        for (int b = 0; b < Cfg::NB; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
-        }
-    }
-    float* An = lds + (cur ^ 1) * STAGE;
-    commit(An, An + BM * LDS_STRIDE);
-    __syncthreads();
-    cur ^= 1;
-    have = have_next;
-  }
-
-  // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ------------------------------------
   // The epilogue-only fields are re-read from kernarg memory here (opaque pointer) so that they do not occupy
   // SGPRs during the K-loop (the whole descriptor live = SGPR spills reloaded every iteration).
   const MsegIgemm* pe = (const MsegIgemm*)__builtin_amdgcn_kernarg_segment_ptr();  // kernel argument 0
@@ -337,6 +153,439 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
   }
 }
 
+template <int BM, int BN, bool PER_SAMPLE, bool GENERIC_ACT>
+__global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
+  using Cfg = IgemmCfg<BM, BN>;
+  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + 4];
+  unsigned* tapmask_s = reinterpret_cast<unsigned*>(lds + 2 * STAGE);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+
+  const int M = p.NB * p.Ho * p.Wo;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  // consecutive workgroups share the A slab (same M tile, different N tile) -> L2 reuse
+  const int tile_m = blockIdx.x / ntiles_n;
+  const int tile_n = blockIdx.x - tile_m * ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int T = p.KH * p.KW;
+  const int srow = tid >> 3;  // staging row within a 32-row pass
+  const int scol = tid & 7;   // float4 column (4 channels)
+
+  const TapGeom geom = make_geom(p);
+  RowInfo rows[Cfg::AROWS];
+#pragma unroll
+  for (int i = 0; i < Cfg::AROWS; ++i) rows[i] = decode_row(p, m0 + srow + 32 * i, M);
+
+  // which taps are live for at least one row of this tile: only a stride-2 transposed conv has dead taps (tile-uniform
+  // under the parity M-order); everywhere else every tap is live and per-row masks handle the borders
+  unsigned tapmask = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
+  if (p.mode == MSEG_MODE_TCONV && p.stride == 2) {
+    if (tid == 0) *tapmask_s = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < Cfg::AROWS; ++i) {
+        int iy, ix;
+        any |= tap_coord(geom, rows[i], ky, kx, iy, ix);
+      }
+      if (any) mine |= (1u << t);
+    }
+    if (mine) atomicOr(tapmask_s, mine);
+    __syncthreads();
+    tapmask = *tapmask_s;
+    __syncthreads();
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+
+  // ---- staging registers: raw loads are issued before the MFMAs of the current step and only *used* (activation,
+  // scale/shift, LDS store) after them, so their latency hides behind the matrix work -------------------------------
+  constexpr int NSC = PER_SAMPLE ? Cfg::AROWS : 1;
+  float4 ra[Cfg::AROWS], rb[Cfg::BROWS], rsc[NSC], rsh[NSC];
+  unsigned amask = 0u;
+  int ract = 0;
+
+  auto issue = [&](int chunk, int t, int ky, int kx) {
+    const int c = chunk * KC + scol * 4;
+    const bool cvalid = c < p.Cin;
+    const bool s1 = (p.nsrc > 1) & (c >= C0);
+    const float* sptr = s1 ? p.src[1].ptr : p.src[0].ptr;
+    const float* sscale = s1 ? p.src[1].scale : p.src[0].scale;
+    const float* sshift = s1 ? p.src[1].shift : p.src[0].shift;
+    const unsigned sC = (unsigned)(s1 ? p.src[1].C : p.src[0].C);
+    const unsigned sss = (unsigned)(s1 ? p.src[1].ss : p.src[0].ss);
+    ract = s1 ? p.src[1].act : p.src[0].act;
+    const unsigned cl = cvalid ? (unsigned)(s1 ? c - C0 : c) : 0u;
+    amask = 0u;
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      int iy, ix;
+      const bool ok = cvalid & tap_coord(geom, rows[i], ky, kx, iy, ix);
+      // pixel index fits 32 bits (M <= 2^31 checked on the host); dead rows read element 0 (always mapped) and are
+      // zeroed at commit time -> no divergent branch around the load
+      const unsigned pix = (unsigned)((rows[i].n * p.Hi + iy) * p.Wi + ix) & (0u - (unsigned)ok);
+      const size_t off = (size_t)pix * sC + (cl & (0u - (unsigned)ok));
+      ra[i] = *reinterpret_cast<const float4*>(sptr + off);
+      amask |= (unsigned)ok << i;
+    }
+    // scale/shift tables, loaded unconditionally (operands without affine use the identity tables)
+    const bool has_aff = sscale != nullptr;
+    const float* scp = has_aff ? sscale : g_ident_scale;
+    const float* shp = has_aff ? sshift : g_ident_shift;
+#pragma unroll
+    for (int i = 0; i < NSC; ++i) {
+      const unsigned n = PER_SAMPLE ? (unsigned)(rows[i].n < 0 ? 0 : rows[i].n) : 0u;
+      const size_t o = (size_t)n * (has_aff ? sss : 0u) + cl;
+      rsc[i] = *reinterpret_cast<const float4*>(scp + o);
+      rsh[i] = *reinterpret_cast<const float4*>(shp + o);
+    }
+    // weights are packed [T][Npad][Kpad] with Npad % 128 == 0 and Kpad % 32 == 0 (zero filled): no bounds checks
+    const float* wt = p.w + ((size_t)t * p.Npad) * p.Kpad;
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(wt + (size_t)(n0 + srow + 32 * i) * p.Kpad + c);
+  };
+
+  auto commit = [&](float* As, float* Bs) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      float4 v = ra[i];
+      if (GENERIC_ACT) {
+        v = act_fwd4(v, ract);
+      } else {
+        v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+      }
+      const float4 sc = rsc[PER_SAMPLE ? i : 0], sh = rsh[PER_SAMPLE ? i : 0];
+      const bool ok = (amask >> i) & 1u;
+      v.x = ok ? v.x * sc.x + sh.x : 0.f;
+      v.y = ok ? v.y * sc.y + sh.y : 0.f;
+      v.z = ok ? v.z * sc.z + sh.z : 0.f;
+      v.w = ok ? v.w * sc.w + sh.w : 0.f;
+      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
+  };
+
+  // K-step iterator (chunk outer, tap inner), by value so that it stays in scalar registers
+  struct Pos { int chunk, t, ky, kx; };
+  const int KWm1 = p.KW - 1;
+  auto advance = [&](Pos q, bool& ok) -> Pos {
+    ok = true;
+    for (;;) {
+      const int wrap = (q.kx == KWm1) ? 1 : 0;
+      q.t += 1;
+      q.kx = wrap ? 0 : q.kx + 1;
+      q.ky += wrap;
+      if (q.t >= T) {
+        q.t = 0; q.ky = 0; q.kx = 0; q.chunk += 1;
+        if (q.chunk >= nchunks) { ok = false; return q; }
+      }
+      if (tapmask & (1u << q.t)) return q;
+    }
+  };
+
+  Pos pos = {0, -1, 0, -1};
+  bool have = false;
+  if (tapmask != 0u) pos = advance(pos, have);
+  int cur = 0;
+  if (have) {
+    issue(pos.chunk, pos.t, pos.ky, pos.kx);
+    commit(lds, lds + BM * LDS_STRIDE);
+  }
+  __syncthreads();
+
+#ifdef MSEG_ABLATE
+  const int abl = p.Cq >> 16;   // bit0: no global loads in the loop, bit1: no barriers, bit2: no MFMA, bit3: no commit
+  if ((abl & 16) && ((blockIdx.x >> 8) & 1)) {   // bit4: stagger the second resident workgroup of a CU by ~half a K-step
+    __builtin_amdgcn_s_sleep(48);
+  }
+  long long t_issue = 0, t_mfma = 0, t_commit = 0, t_bar = 0;   // bit5: per-phase cycle stamps (diagnostic build only)
+#define STAMP(var) do { if (abl & 32) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+  long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#else
+#define STAMP(var)
+#endif
+  const int li = lane & 31, lh = lane >> 5;
+  while (have) {
+    // prefetch the next K-step (on the last step: a harmless re-read of the current one, keeps the body branch-free)
+    bool have_next;
+    const Pos nxt = advance(pos, have_next);
+    if (have_next) pos = nxt;
+    STAMP(s0);
+#ifdef MSEG_ABLATE
+    if (!(abl & 1))
+#endif
+    issue(pos.chunk, pos.t, pos.ky, pos.kx);
+    STAMP(s1);
+
+    const float* As = lds + cur * STAGE;
+    const float* Bs = As + BM * LDS_STRIDE;
+#pragma unroll
+    for (int kk = 0; kk < KC / 8; ++kk) {
+      float4 af[Cfg::MB], bf[Cfg::NB];
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+        af[a] = *reinterpret_cast<const float4*>(As + (wm * Cfg::TM + a * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+      for (int b = 0; b < Cfg::NB; ++b)
+        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn * Cfg::TN + b * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#ifdef MSEG_ABLATE
+      if (abl & 4) { asm volatile("" :: "v"(af[0].x), "v"(bf[0].x)); continue; }
+#endif
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+        for (int b = 0; b < Cfg::NB; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+    float* An = lds + (cur ^ 1) * STAGE;
+#ifdef MSEG_ABLATE
+    STAMP(s2);
+    if (!(abl & 8)) commit(An, An + BM * LDS_STRIDE);
+    STAMP(s3);
+    if (!(abl & 2)) __syncthreads();
+    STAMP(s4);
+    t_issue += s1 - s0; t_mfma += s2 - s1; t_commit += s3 - s2; t_bar += s4 - s3;
+#else
+    commit(An, An + BM * LDS_STRIDE);
+    __syncthreads();
+#endif
+    cur ^= 1;
+    have = have_next;
+  }
+
+#ifdef MSEG_ABLATE
+  if ((abl & 32) && p.dst1 && lane == 0 && blockIdx.x < 1024) {
+    float* dbg = p.dst1 + ((size_t)blockIdx.x * 4 + wave) * 4;
+    dbg[0] = (float)t_issue; dbg[1] = (float)t_mfma; dbg[2] = (float)t_commit; dbg[3] = (float)t_bar;
+  }
+#endif
+  igemm_epilogue<BM, BN>(acc, m0, n0, wm, wn, lane, M);
+}
+
+// =====================================================================================================================
+// Fast path.  Measured on MI355X (tools/ubench/mfma_valu.hip): v_mfma_f32_32x32x2_f32 does NOT co-execute with VALU
+// work — an fp32-MFMA wave and a VALU wave on one SIMD take the SUM of their times (the f32 matrix op runs at the
+// vector rate on shared hardware).  Every VALU instruction in the K-loop is therefore paid in MFMA throughput, and
+// the staging code is written to issue as few as possible:
+//   * per-row source offsets (bytes, 32 bit) and a per-row tap-validity bit mask are computed once per tile; a K-step
+//     needs one v_add (wave-uniform tap delta) + bit test + select per staged row, no multiplies, no 64-bit math;
+//   * loads go through buffer descriptors: 32-bit voffset, dead rows use an out-of-range offset and come back as 0;
+//   * weight rows need no per-step VALU at all (constant voffset, the step offset is the scalar soffset);
+//   * scale/shift tables are fetched once per 32-channel chunk, not once per tap;
+//   * operands without transform (all dgrad launches) are committed to LDS untouched.
+// Preconditions (checked on the host, otherwise the generic kernel above runs): CONV mode or stride-1 TCONV, every
+// operand < 2 GiB, and the concat boundary C0 a multiple of 32 (wave-uniform source selection).
+// TR: 0 = plain operand, 1 = none/ReLU + affine, 2 = any activation + affine.
+template <int BM, int BN, int TR, bool PER_SAMPLE>
+__global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
+  using Cfg = IgemmCfg<BM, BN>;
+  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int M = p.NB * p.Ho * p.Wo;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  const int tile_m = blockIdx.x / ntiles_n;
+  const int tile_n = blockIdx.x - tile_m * ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int T = p.KH * p.KW;
+  const int srow = tid >> 3, scol = tid & 7;
+
+  // ---- per-row geometry, once per tile ------------------------------------------------------------------------
+  const TapGeom geom = make_geom(p);
+  int pix0[Cfg::AROWS];            // source pixel index of tap (0,0); meaningful only where a tap is live
+  int rown[Cfg::AROWS];            // image index (per-sample tables)
+  unsigned vmask[Cfg::AROWS];      // bit t set <=> tap t of this row reads a real source pixel
+#pragma unroll
+  for (int i = 0; i < Cfg::AROWS; ++i) {
+    const RowInfo r = decode_row(p, m0 + srow + 32 * i, M);
+    const int iy0 = r.oy * geom.sm - geom.dir * geom.pad, ix0 = r.ox * geom.sm - geom.dir * geom.pad;
+    pix0[i] = (r.n * p.Hi + iy0) * p.Wi + ix0;
+    rown[i] = r.n < 0 ? 0 : r.n;
+    unsigned mk = 0u;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      int iy, ix;
+      mk |= (unsigned)tap_coord(geom, r, ky, kx, iy, ix) << t;
+    }
+    vmask[i] = mk;
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+  const unsigned OOB = 0x80000000u;   // >= num_records of every descriptor (operands are < 2 GiB)
+
+  // wave-uniform buffer descriptors (kernarg-derived only)
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0,
+                                                                        p.NB * p.Hi * p.Wi * p.src[0].C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr), 0,
+      p.NB * p.Hi * p.Wi * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                        T * p.Npad * p.Kpad * 4, 0x00020000);
+  unsigned wvoff[Cfg::BROWS];
+#pragma unroll
+  for (int i = 0; i < Cfg::BROWS; ++i) wvoff[i] = ((unsigned)(n0 + srow + 32 * i) * (unsigned)p.Kpad + scol * 4u) * 4u;
+
+  // ---- staging state ---------------------------------------------------------------------------------------------
+  constexpr int NSC = (TR == 0) ? 1 : (PER_SAMPLE ? Cfg::AROWS : 1);
+  float4 ra[Cfg::AROWS], rb[Cfg::BROWS], rsc[NSC], rsh[NSC];
+  float rm[Cfg::AROWS];              // 1.0 for live rows, 0.0 for padding / tail rows (TR != 0)
+  unsigned rowoff[Cfg::AROWS];       // byte offset of (tap (0,0), this thread's channel quad) in the current source
+  int ract = 0;
+  int cur_chunk = -1;
+  bool cur_s1 = false;
+
+  auto issue = [&](int chunk, int t, int ky, int kx) {
+    const int c = chunk * KC + scol * 4;
+    if (chunk != cur_chunk) {        // wave-uniform: new 32-channel chunk -> source select, row offsets, tables
+      cur_chunk = chunk;
+      cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
+      const unsigned sC4 = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * 4u;
+      const unsigned cl4 = (unsigned)(cur_s1 ? c - C0 : c) * 4u;
+#pragma unroll
+      for (int i = 0; i < Cfg::AROWS; ++i) rowoff[i] = (unsigned)pix0[i] * sC4 + cl4;
+      if (TR != 0) {
+        const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
+        ract = s.act;
+        const bool has_aff = s.scale != nullptr;
+        const float* scp = has_aff ? s.scale : g_ident_scale;
+        const float* shp = has_aff ? s.shift : g_ident_shift;
+        const unsigned cl = (c < p.Cin) ? (cl4 >> 2) : 0u;
+#pragma unroll
+        for (int i = 0; i < NSC; ++i) {
+          const size_t o = (size_t)(PER_SAMPLE ? rown[i] : 0) * (has_aff ? (unsigned)s.ss : 0u) + cl;
+          rsc[i] = *reinterpret_cast<const float4*>(scp + o);
+          rsh[i] = *reinterpret_cast<const float4*>(shp + o);
+        }
+      }
+    }
+    const unsigned cbit = (c < p.Cin) ? (1u << t) : 0u;                      // channel tail of the last chunk
+    const unsigned sC4 = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * 4u;   // scalar
+    const unsigned delta = (unsigned)(geom.dir * (ky * p.Wi + kx)) * sC4;     // scalar, wraps mod 2^32 by design
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      const bool ok = (vmask[i] & cbit) != 0u;
+      const unsigned vo = ok ? rowoff[i] + delta : OOB;
+      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+      ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      if (TR != 0) rm[i] = ok ? 1.f : 0.f;
+    }
+    const unsigned wso = ((unsigned)t * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC) * 4u;   // scalar
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], wso, 0));
+      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+
+  auto commit = [&](float* As, float* Bs) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int i = 0; i < Cfg::AROWS; ++i) {
+      float4 v = ra[i];
+      if (TR != 0) {
+        if (TR == 2) {
+          v = act_fwd4(v, ract);
+        } else {
+          v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo);
+        }
+        const float4 sc = rsc[PER_SAMPLE ? i : 0], sh = rsh[PER_SAMPLE ? i : 0];
+        const float m = rm[i];
+        v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+        v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+      }
+      *reinterpret_cast<float4*>(As + (srow + 32 * i) * LDS_STRIDE + scol * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
+  };
+
+  // K-step iterator: chunk outer, tap inner; every tap is live for at least one row in CONV / stride-1 TCONV
+  int chunk = 0, t = 0, ky = 0, kx = 0;
+  const int KWm1 = p.KW - 1;
+  const int nsteps = nchunks * T;
+  issue(0, 0, 0, 0);
+  commit(lds, lds + BM * LDS_STRIDE);
+  __syncthreads();
+  int cur = 0;
+  const int li = lane & 31, lh = lane >> 5;
+  for (int step = 0; step < nsteps; ++step) {
+    // prefetch the next K-step (the last iteration re-reads the current one: keeps the body branch-free)
+    if (step + 1 < nsteps) {
+      const int wrap = (kx == KWm1) ? 1 : 0;
+      t += 1; kx = wrap ? 0 : kx + 1; ky += wrap;
+      if (t >= T) { t = 0; ky = 0; kx = 0; ++chunk; }
+    }
+    issue(chunk, t, ky, kx);
+
+    const float* As = lds + cur * STAGE;
+    const float* Bs = As + BM * LDS_STRIDE;
+#pragma unroll
+    for (int kk = 0; kk < KC / 8; ++kk) {
+      float4 af[Cfg::MB], bf[Cfg::NB];
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+        af[a] = *reinterpret_cast<const float4*>(As + (wm * Cfg::TM + a * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+      for (int b = 0; b < Cfg::NB; ++b)
+        bf[b] = *reinterpret_cast<const float4*>(Bs + (wn * Cfg::TN + b * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+        for (int b = 0; b < Cfg::NB; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+    float* An = lds + (cur ^ 1) * STAGE;
+    commit(An, An + BM * LDS_STRIDE);
+    __syncthreads();
+    cur ^= 1;
+  }
+  igemm_epilogue<BM, BN>(acc, m0, n0, wm, wn, lane, M);
+}
+
 static int check_src(const MsegSrc& s) {
   if (!s.ptr || s.C <= 0 || (s.C & 3)) return MSEG_EINVAL;
   if ((s.scale == nullptr) != (s.shift == nullptr)) return MSEG_EINVAL;
@@ -354,7 +603,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     csum += p.src[i].C;
   }
   if (csum != p.Cin) return MSEG_EINVAL;
-  if (!p.w || !p.dst0 || p.Kpad < p.Cin || (p.Kpad & 3)) return MSEG_EINVAL;
+  if (!p.w || !p.dst0 || p.Kpad < p.Cin || (p.Kpad % KC) || p.Npad < p.Ngemm || (p.Npad % 128)) return MSEG_EINVAL;
+  if (p.Cin > MSEG_MAX_CH) return MSEG_EINVAL;
   if (p.NB <= 0 || p.Hi <= 0 || p.Wi <= 0 || p.Ho <= 0 || p.Wo <= 0) return MSEG_EINVAL;
   if (p.KH <= 0 || p.KW <= 0 || p.KH * p.KW > 16) return MSEG_EINVAL;
   if (p.stride != 1 && p.stride != 2) return MSEG_EINVAL;
@@ -371,6 +621,15 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long M = (long long)p.NB * p.Ho * p.Wo;
   if (M <= 0 || M > 0x7fffffffLL) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  // one-off, idempotent fill of the per-device identity tables (concurrent first calls write the same values)
+  static bool ident_ready[64] = {false};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
+  if (!ident_ready[devid]) {
+    hipLaunchKernelGGL(init_ident_kernel, dim3(8), dim3(256), 0, st);
+    MSEG_LAUNCH_CHECK();
+    ident_ready[devid] = true;
+  }
   bool per_sample = false, generic = false;
   for (int i = 0; i < p.nsrc; ++i) {
     if (p.src[i].scale && p.src[i].ss != 0) per_sample = true;
@@ -381,6 +640,31 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long tiles = ((M + BMv - 1) / BMv) * ((p.Ngemm + BNv - 1) / BNv);
   if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
   const dim3 grid((unsigned)tiles), block(256);
+  // fast path preconditions (see igemm_fast_kernel)
+  bool fast = (p.mode == MSEG_MODE_CONV) || (p.stride == 1);
+  bool plain = true;
+  for (int i = 0; i < p.nsrc; ++i) {
+    if ((long long)p.NB * p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) fast = false;
+    if (p.src[i].act != MSEG_ACT_NONE || p.src[i].scale) plain = false;
+  }
+  if ((long long)p.KH * p.KW * p.Npad * p.Kpad * 4 >= 0x80000000LL) fast = false;
+  if (p.nsrc > 1 && (p.src[0].C % KC)) fast = false;
+  if (fast) {
+    const int tr = plain ? 0 : (generic ? 2 : 1);
+#define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_) \
+  hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_>), grid, block, 0, st, p)
+#define MSEG_FAST_TILE(BM_, BN_)                                                          \
+  do {                                                                                    \
+    if (tr == 0) MSEG_FAST_LAUNCH(BM_, BN_, 0, false);                                    \
+    else if (tr == 1) { if (per_sample) MSEG_FAST_LAUNCH(BM_, BN_, 1, true); else MSEG_FAST_LAUNCH(BM_, BN_, 1, false); } \
+    else { if (per_sample) MSEG_FAST_LAUNCH(BM_, BN_, 2, true); else MSEG_FAST_LAUNCH(BM_, BN_, 2, false); }              \
+  } while (0)
+    if (wide) MSEG_FAST_TILE(128, 128); else MSEG_FAST_TILE(128, 64);
+#undef MSEG_FAST_TILE
+#undef MSEG_FAST_LAUNCH
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
 #define MSEG_IGEMM_LAUNCH(BM_, BN_, PS_, GA_) \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, PS_, GA_>), grid, block, 0, st, p)
   if (wide) {
@@ -396,26 +680,26 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
 }
 
 // ---- weight repack ------------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int R, int C,
-                                   int Cpad, int st, int sr, int sc) {
-  const size_t total = (size_t)T * R * Cpad;
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int R, int Rpad,
+                                   int C, int Cpad, int st, int sr, int sc) {
+  const size_t total = (size_t)T * Rpad * Cpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cpad);
     const size_t tr = i / Cpad;
-    const int r = (int)(tr % R);
-    const int t = (int)(tr / R);
-    dst[i] = c < C ? src[(size_t)t * st + (size_t)r * sr + (size_t)c * sc] : 0.f;
+    const int r = (int)(tr % Rpad);
+    const int t = (int)(tr / Rpad);
+    dst[i] = (c < C && r < R) ? src[(size_t)t * st + (size_t)r * sr + (size_t)c * sc] : 0.f;
   }
 }
 
-extern "C" int mseg_pack_weight(const float* src, float* dst, int T, int R, int C, int Cpad, int st, int sr, int sc,
-                                void* stream) {
-  if (!src || !dst || T <= 0 || R <= 0 || C <= 0 || Cpad < C || (Cpad & 3)) return MSEG_EINVAL;
-  const size_t total = (size_t)T * R * Cpad;
+extern "C" int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C, int Cpad, int st, int sr,
+                                int sc, void* stream) {
+  if (!src || !dst || T <= 0 || R <= 0 || Rpad < R || C <= 0 || Cpad < C || (Cpad & 3)) return MSEG_EINVAL;
+  const size_t total = (size_t)T * Rpad * Cpad;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096u) blocks = 4096u;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, T, R, C, Cpad, st,
-                     sr, sc);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, T, R, Rpad, C,
+                     Cpad, st, sr, sc);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

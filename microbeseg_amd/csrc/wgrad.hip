@@ -15,6 +15,13 @@
 #define WG_PIX 32
 #define WG_LDS 68
 
+// identity affine for operands without tables (filled once per device by the launcher)
+__device__ float g_wg_ident_scale[4];
+__device__ float g_wg_ident_shift[4];
+__global__ void wgrad_init_ident_kernel() {
+  if (threadIdx.x < 4) { g_wg_ident_scale[threadIdx.x] = 1.f; g_wg_ident_shift[threadIdx.x] = 0.f; }
+}
+
 // KWT = taps handled by one workgroup (= one kernel row ky = blockIdx.z): 3 for the 3x3 convs, 2 for the 2x2 convT.
 template <int KWT, bool GENERIC_ACT, bool PER_SAMPLE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int splits, int steps_per_split) {
@@ -185,6 +192,189 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   }
 }
 
+// =====================================================================================================================
+// Fast path (same reasoning as igemm_fast_kernel: fp32 MFMA and VALU share the SIMD's execution time, so the staging
+// code is stripped of multiplies, divisions and 64-bit address math):
+//   * pixel coordinates and byte offsets of the two staged pixels per thread advance incrementally (+32 pixels per
+//     step) with wave-uniform increments and carries; one division per kernel, none per step;
+//   * buffer-descriptor loads with 32-bit offsets, out-of-range offset for padding taps / the pixel tail (returns 0);
+//   * P (the output gradient dz of a conv, or the convT input) and Q are transformed only if they carry a transform
+//     (PTR / QTR: 0 plain, 1 none|ReLU + affine, 2 any activation + affine).
+// Preconditions (host): operands < 2 GiB, per-channel (not per-sample) tables, concat boundary multiple of 64.
+template <int KWT, int PTR, int QTR>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int splits, int steps_per_split) {
+  constexpr int SLAB = WG_PIX * WG_LDS;
+  constexpr int STAGE = (1 + KWT) * SLAB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Mch = p.P.C, Nch = p.Nch;
+  const int T = p.KH * p.KW;
+  const int ntiles_n = (Nch + 63) / 64;
+  const int mt = blockIdx.x / ntiles_n, nt = blockIdx.x - mt * ntiles_n;
+  const int split = blockIdx.y;
+  const int ky = blockIdx.z;
+
+  const int Ptot = p.NB * p.Hp * p.Wp;
+  const int pix_begin = split * steps_per_split * WG_PIX;
+  int pix_end = pix_begin + steps_per_split * WG_PIX;
+  if (pix_end > Ptot) pix_end = Ptot;
+  const int nsteps = pix_end > pix_begin ? (pix_end - pix_begin + WG_PIX - 1) / WG_PIX : 0;
+
+  f32x16 acc[KWT];
+#pragma unroll
+  for (int t = 0; t < KWT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int spx = tid >> 4, sc4 = tid & 15;
+  const int mc = mt * 64 + sc4 * 4;
+  const int qc = nt * 64 + sc4 * 4;
+  const bool q1 = (p.nq > 1) && (nt * 64 >= p.Q[0].C);      // wave-uniform (concat boundary is a multiple of 64)
+  const MsegSrc& qs = q1 ? p.Q[1] : p.Q[0];
+  const bool mvalid = mc < Mch, qvalid = qc < Nch;
+  const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
+  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
+  const unsigned OOB = 0x80000000u;
+
+  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, Ptot * Mch * 4,
+                                                                        0x00020000);
+  const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(qs.ptr), 0, p.NB * p.Hq * p.Wq * qs.C * 4, 0x00020000);
+
+  // per-channel tables: this thread's channel quad is fixed for the whole kernel
+  float4 psc, psh, qsc, qsh;
+  {
+    const float* a = (PTR && p.P.scale) ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
+    const float* b = (PTR && p.P.scale) ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
+    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
+    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
+    psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
+    qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
+  }
+  const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+  const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+
+  // ---- incremental pixel state of the two staged pixels (rows spx and spx + 16 of the 32-pixel step) ---------
+  // pp: flat pixel index; (py, px): position in its image; qoff: byte offset of the Q pixel
+  // (py*stride + ky - pad, px*stride - pad) + this thread's channel quad in the current Q source.
+  const int adv_y = WG_PIX / p.Wp, adv_x = WG_PIX - adv_y * p.Wp;              // +32 pixels = adv_y rows + adv_x cols
+  const int q_dx = p.stride * (int)qC4;                                        // one column right in P -> bytes in Q
+  const int q_dy = p.stride * p.Wq * (int)qC4;                                 // one row down in P
+  const int q_wrap_x = -p.Wp * q_dx + q_dy;                                    // column carry
+  const int q_wrap_y = -p.Hp * q_dy + p.Hq * p.Wq * (int)qC4;                  // row carry into the next image
+  int pp[2], py[2], px[2];
+  unsigned qoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int v = pix_begin + spx + 16 * i;
+    if (v >= Ptot) v = Ptot - 1;                      // tail rows: any valid pixel; they are masked by pp >= pix_end
+    pp[i] = pix_begin + spx + 16 * i;
+    const int n = v / (p.Hp * p.Wp);
+    const int rem = v - n * (p.Hp * p.Wp);
+    py[i] = rem / p.Wp; px[i] = rem - py[i] * p.Wp;
+    qoff[i] = (unsigned)(((n * p.Hq + py[i] * p.stride + ky - p.pad) * p.Wq + px[i] * p.stride - p.pad) * (int)qC4) + qcl4;
+  }
+  const unsigned pvoff0 = (unsigned)spx * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
+
+  float4 rp[2], rq[KWT][2];
+  float pm[2], qm[KWT][2];
+
+  auto issue = [&](int step) {          // loads of `step`; then advances the pixel state to step + 1
+    const unsigned psoff = (unsigned)(pix_begin + step * WG_PIX) * mC4;        // scalar
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool inr = pp[i] < pix_end;
+      const bool pok = inr & mvalid;
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rsp, pok ? pvoff0 + (unsigned)(16 * i) * mC4 : OOB, psoff, 0));
+      rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+      if (PTR) pm[i] = pok ? 1.f : 0.f;
+      const int qy = py[i] * p.stride + ky - p.pad;
+      const bool yok = inr & qvalid & (qy >= 0) & (qy < p.Hq);
+      const int qx0 = px[i] * p.stride - p.pad;
+#pragma unroll
+      for (int kx = 0; kx < KWT; ++kx) {
+        const bool ok = yok & (qx0 + kx >= 0) & (qx0 + kx < p.Wq);
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsq, ok ? qoff[i] + (unsigned)kx * qC4 : OOB, 0, 0));
+        rq[kx][i] = make_float4(q[0], q[1], q[2], q[3]);
+        if (QTR) qm[kx][i] = ok ? 1.f : 0.f;
+      }
+      // advance by 32 pixels (wave-uniform increments, per-lane carries)
+      pp[i] += WG_PIX;
+      px[i] += adv_x; py[i] += adv_y;
+      qoff[i] += (unsigned)(adv_x * q_dx + adv_y * q_dy);
+      const bool cx = px[i] >= p.Wp;
+      px[i] -= cx ? p.Wp : 0; py[i] += cx ? 1 : 0;
+      qoff[i] += cx ? (unsigned)q_wrap_x : 0u;
+      while (py[i] >= p.Hp) { py[i] -= p.Hp; qoff[i] += (unsigned)q_wrap_y; }
+    }
+  };
+
+  auto xf = [&](float4 v, const float4& sc, const float4& sh, float m, int act, float lo, int tr) -> float4 {
+    if (tr == 0) return v;
+    if (tr == 2) v = act_fwd4(v, act);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+
+  auto commit = [&](float* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* row = stage + (spx + 16 * i) * WG_LDS + sc4 * 4;
+      *reinterpret_cast<float4*>(row) = xf(rp[i], psc, psh, PTR ? pm[i] : 1.f, p.P.act, plo, PTR);
+#pragma unroll
+      for (int kx = 0; kx < KWT; ++kx)
+        *reinterpret_cast<float4*>(row + (1 + kx) * SLAB) =
+            xf(rq[kx][i], qsc, qsh, QTR ? qm[kx][i] : 1.f, qs.act, qlo, QTR);
+    }
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    commit(lds);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    issue(step + 1);                                  // beyond the last step every row is >= pix_end -> all zeros
+    const float* st = lds + buf * STAGE;
+    float a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WG_LDS + wm * 32 + li];
+#pragma unroll
+    for (int kx = 0; kx < KWT; ++kx) {
+      const float* Qb = st + (1 + kx) * SLAB;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float b = Qb[(2 * kk + lh) * WG_LDS + wn * 32 + li];
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
+      }
+    }
+    commit(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int n = nt * 64 + wn * 32 + li;
+  if (n < Nch) {
+#pragma unroll
+    for (int kx = 0; kx < KWT; ++kx) {
+      const int t = ky * KWT + kx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < Mch) p.ws[(((size_t)split * T + t) * Mch + m) * Nch + n] = acc[kx][r];
+      }
+    }
+  }
+}
+
 // dst[(m*Nst + n)*T + t] = sum_s ws[((s*T + t)*Mch + m)*Nch + n]   (fixed order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dst, int splits, int T,
                                     int Mch, int Nch, int Nst) {
@@ -254,6 +444,36 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       if (p.Q[i].scale && p.Q[i].ss != 0) per_sample = true;
     }
     const dim3 grid(tiles, splits, p.KH), block(256);
+    // fast path preconditions (see wgrad_fast_kernel)
+    const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
+    bool fast = !per_sample && Ptot64 * p.P.C * 4 < 0x80000000LL && (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
+    for (int i = 0; i < p.nq; ++i)
+      if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) fast = false;
+    if (p.nq > 1 && (p.Q[0].C % 64)) fast = false;
+    if (fast) {
+      static bool ident_ready[64] = {false};
+      int devid = 0;
+      if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
+      if (!ident_ready[devid]) {
+        hipLaunchKernelGGL(wgrad_init_ident_kernel, dim3(1), dim3(64), 0, st);
+        MSEG_LAUNCH_CHECK();
+        ident_ready[devid] = true;
+      }
+      auto tr_of = [](const MsegSrc& s) {
+        if (s.act == MSEG_ACT_NONE && !s.scale) return 0;
+        return (s.act == MSEG_ACT_NONE || s.act == MSEG_ACT_RELU) ? 1 : 2;
+      };
+      const int ptr = tr_of(p.P);
+      int qtr = 0;
+      for (int i = 0; i < p.nq; ++i) { const int v = tr_of(p.Q[i]); if (v > qtr) qtr = v; }
+#define MSEG_WF(KW_, P_, Q_) hipLaunchKernelGGL((wgrad_fast_kernel<KW_, P_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WF_Q(KW_, P_) do { if (qtr == 0) MSEG_WF(KW_, P_, 0); else if (qtr == 1) MSEG_WF(KW_, P_, 1); else MSEG_WF(KW_, P_, 2); } while (0)
+#define MSEG_WF_P(KW_) do { if (ptr == 0) MSEG_WF_Q(KW_, 0); else if (ptr == 1) MSEG_WF_Q(KW_, 1); else MSEG_WF_Q(KW_, 2); } while (0)
+      if (p.KW == 3) MSEG_WF_P(3); else MSEG_WF_P(2);
+#undef MSEG_WF_P
+#undef MSEG_WF_Q
+#undef MSEG_WF
+    } else {
 #define MSEG_WGRAD_LAUNCH(KW_, GA_, PS_) \
   hipLaunchKernelGGL((wgrad_kernel<KW_, GA_, PS_>), grid, block, 0, st, p, splits, sps)
     if (p.KW == 3) {
@@ -264,6 +484,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       else         { if (per_sample) MSEG_WGRAD_LAUNCH(2, false, true); else MSEG_WGRAD_LAUNCH(2, false, false); }
     }
 #undef MSEG_WGRAD_LAUNCH
+    }
     MSEG_LAUNCH_CHECK();
   }
   if (p.phase == 1) return MSEG_OK;

@@ -116,14 +116,36 @@ def set_kernel_timer(t):
 
 
 # ---- thin kernel wrappers ------------------------------------------------------------------------------------
-def pack_weight(src, T, R, Cc, Cpad, st, sr, sc):
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class PackedW:
+    """GEMM operand [T][Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero filled) produced by pack_weight."""
+    __slots__ = ("t", "Npad", "Kpad")
+
+    def __init__(self, t, Npad, Kpad):
+        self.t, self.Npad, self.Kpad = t, Npad, Kpad
+
+
+def pack_weight(src, T, R, Cc, st, sr, sc, merge_taps=False):
+    """dst[(t*Rpad + r)*Kpad + c] = src[t*st + r*sr + c*sc], zero padded.  merge_taps: the T blocks of R rows are
+    laid out back to back (one GEMM with N = T*R: ConvTranspose2d as a 1x1 GEMM) and padded as a whole."""
     lib = _lib.load()
-    dst = torch.empty(T * R * Cpad, dtype=torch.float32, device=src.device)
-    check(lib.mseg_pack_weight(src.data_ptr(), dst.data_ptr(), T, R, Cc, Cpad, st, sr, sc, _stream()), "pack_weight")
-    return dst
+    kpad = _round_up(Cc, 32)
+    if merge_taps:
+        npad = _round_up(T * R, 128)
+        dst = torch.zeros(npad * kpad, dtype=torch.float32, device=src.device)
+        rpad = R
+    else:
+        npad = rpad = _round_up(R, 128)
+        dst = torch.empty(T * npad * kpad, dtype=torch.float32, device=src.device)
+    check(lib.mseg_pack_weight(src.data_ptr(), dst.data_ptr(), T, R, rpad, Cc, kpad, st, sr, sc, _stream()),
+          "pack_weight")
+    return PackedW(dst, npad, kpad)
 
 
-def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, Kpad, dst0, ld0, acc0=0,
+def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, dst0, ld0, acc0=0,
           dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, real_cin=None):
     lib = _lib.load()
     p = MsegIgemm()
@@ -131,8 +153,9 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, K
         p.src[i] = s
     p.nsrc = len(srcs)
     p.Cin = sum(s.C for s in srcs)
-    p.Kpad = Kpad
-    p.w = w.data_ptr()
+    p.Kpad = w.Kpad
+    p.Npad = w.Npad
+    p.w = w.t.data_ptr()
     p.bias = _ptr(bias)
     p.dst0 = dst0.data_ptr()
     p.dst1 = _ptr(dst1)
@@ -300,11 +323,10 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
     if spec.kind == "up":
         cin, cout = wt.shape[0], wt.shape[1]
         assert cin == cin_total
-        kp = _pad4(cin)
-        wp = pack_weight(wt, 4, cout, cin, kp, 1, 4, cout * 4)
+        wp = pack_weight(wt, 4, cout, cin, 1, 4, cout * 4, merge_taps=True)
         Ho, Wo = 2 * Hi, 2 * Wi
         z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        igemm(srcs, wp, bias, N, Hi, Wi, Hi, Wi, 1, 1, 1, 0, MODE_CONV, 4 * cout, kp, z, cout,
+        igemm(srcs, wp, bias, N, Hi, Wi, Hi, Wi, 1, 1, 1, 0, MODE_CONV, 4 * cout, z, cout,
               epi=EPI_SCATTER2X2, Cq=cout)
         act = ACT["none"]
     else:
@@ -314,11 +336,10 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
             assert cin == cin_total, (cin, cin_total)
         else:
             assert _pad4(cin) == cin_total, (cin, cin_total)   # network input is zero-padded to 4 channels
-        kp = _pad4(cin_total)
-        wp = pack_weight(wt, 9, cout, cin, kp, 1, cin * 9, 9)
+        wp = pack_weight(wt, 9, cout, cin, 1, cin * 9, 9)
         Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
         z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, kp, z, cout, real_cin=cin)
+        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
         act = spec.act
     node = Node(z, N, Ho, Wo, cout)
     node.act = act
@@ -448,10 +469,10 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
             # dW[ci][co][a][b] = sum x[p][ci] * dz[2p+(a,b)][co]
             wgrad(i0.src(), [plain_src(dz, cout)], dW, N, i0.H, i0.W, node.H, node.W, 2, 2, 2, 0, ws)
             # dx[p][ci] = sum_{ab,co} dz[2p+(a,b)][co] * W[ci][co][a][b]
-            wp = pack_weight(wt, 4, cin, cout, _pad4(cout), 1, cout * 4, 4)
+            wp = pack_weight(wt, 4, cin, cout, 1, cout * 4, 4)
             tgt, acc = _accumulate_target(i0, None)
             igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 2, 2, 2, 0, MODE_CONV, cin,
-                  _pad4(cout), tgt, cin, acc0=acc)
+                  tgt, cin, acc0=acc)
         else:
             cout, cin = wt.shape[0], wt.shape[1]
             stride = 2 if sp.kind == "pool" else 1
@@ -459,18 +480,18 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
             wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
                   ws, nch_store=cin if is_first else None)
             if not is_first:
-                wp = pack_weight(wt, 9, cin, cout, _pad4(cout), 1, 9, cin * 9)
+                wp = pack_weight(wt, 9, cin, cout, 1, 9, cin * 9)
                 morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
                 if len(ins) == 1:
                     tgt, acc = _accumulate_target(i0, None)
                     igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
-                          MODE_TCONV, cin, _pad4(cout), tgt, cin, acc0=acc, morder=morder)
+                          MODE_TCONV, cin, tgt, cin, acc0=acc, morder=morder)
                 else:
                     i1 = ins[1]
                     t0, a0 = _accumulate_target(i0, None)
                     t1, a1 = _accumulate_target(i1, None)
                     igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
-                          MODE_TCONV, cin, _pad4(cout), t0, i0.C, acc0=a0, dst1=t1, ld1=i1.C, acc1=a1,
+                          MODE_TCONV, cin, t0, i0.C, acc0=a0, dst1=t1, ld1=i1.C, acc1=a1,
                           split=i0.C, morder=morder)
         grads[id(conv.weight)] = dW
         if on_grads is not None:        # data-parallel: gradients of this layer are final -> start their all-reduce

@@ -72,10 +72,10 @@ def test_conv3x3_forward(eng, N, Cin, Cout, H, W, stride, act):
     w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
     ref = F.conv2d(_transform_cpu(z, act, scale, shift, True), w, b, stride=stride, padding=1)
     node = _mk_node(eng, z, act, scale, shift, per_sample=True)
-    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, Cin, 1, Cin * 9, 9)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
     Ho, Wo = ref.shape[2], ref.shape[3]
     out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
-    eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, Cout, Cin, out, Cout)
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, Cout, out, Cout)
     assert rel_err(nchw(out.cpu()), ref) < TOL
 
 
@@ -90,9 +90,9 @@ def test_conv3x3_concat_two_sources(eng):
     ref = F.conv2d(x, w, b, padding=1)
     n0 = _mk_node(eng, z0, "none", s0, h0, False)
     n1 = _mk_node(eng, z1, "relu", s1, h1, True)
-    wp = eng.pack_weight(w.cuda(), 9, Cout, C0 + C1, C0 + C1, 1, (C0 + C1) * 9, 9)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, C0 + C1, 1, (C0 + C1) * 9, 9)
     out = torch.empty((N, H, W, Cout), device="cuda")
-    eng.igemm([n0.src(), n1.src()], wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, C0 + C1, out, Cout)
+    eng.igemm([n0.src(), n1.src()], wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout)
     assert rel_err(nchw(out.cpu()), ref) < TOL
 
 
@@ -107,19 +107,19 @@ def test_conv3x3_dgrad(eng, N, Cin, Cout, H, W, stride):
     gy = rnd(g, *y.shape)
     y.backward(gy)
     ref = x.grad
-    wp = eng.pack_weight(w.cuda(), 9, Cin, Cout, Cout, 1, 9, Cin * 9)
+    wp = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
     Ho, Wo = y.shape[2], y.shape[3]
     dz = nhwc(gy).cuda()
     out = torch.full((N, H, W, Cin), float("nan"), device="cuda")
     morder = eng.MORDER_PARITY if stride == 2 else eng.MORDER_LINEAR
-    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, Cout, out, Cin,
+    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, out, Cin,
               morder=morder)
     assert rel_err(nchw(out.cpu()), ref) < TOL
     # accumulate flag + split destinations
     base = rnd(g, N, H, W, Cin)
     c0 = Cin // 2 // 4 * 4 or 4
     d0, d1 = base[..., :c0].contiguous().cuda(), base[..., c0:].contiguous().cuda()
-    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, Cout, d0, c0,
+    eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.MODE_TCONV, Cin, d0, c0,
               acc0=1, dst1=d1, ld1=Cin - c0, acc1=0, split=c0, morder=morder)
     refn = nhwc(ref)
     assert rel_err(d0.cpu(), refn[..., :c0] + base[..., :c0]) < TOL
@@ -135,15 +135,15 @@ def test_conv_transpose_forward_and_dgrad(eng, N, Cin, Cout, H, W):
     gy = rnd(g, *y.shape)
     y.backward(gy)
     node = _mk_node(eng, x.detach())
-    wp = eng.pack_weight(w.cuda(), 4, Cout, Cin, Cin, 1, 4, Cout * 4)
+    wp = eng.pack_weight(w.cuda(), 4, Cout, Cin, 1, 4, Cout * 4, merge_taps=True)
     out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
-    eng.igemm([node.src()], wp, b.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, Cin, out, Cout,
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, out, Cout,
               epi=eng.EPI_SCATTER2X2, Cq=Cout)
     assert rel_err(nchw(out.cpu()), y.detach()) < TOL
-    wd = eng.pack_weight(w.cuda(), 4, Cin, Cout, Cout, 1, Cout * 4, 4)
+    wd = eng.pack_weight(w.cuda(), 4, Cin, Cout, 1, Cout * 4, 4)
     dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
     dz = nhwc(gy).cuda()
-    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, 2 * H, 2 * W, H, W, 2, 2, 2, 0, eng.MODE_CONV, Cin, Cout, dx, Cin)
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, 2 * H, 2 * W, H, W, 2, 2, 2, 0, eng.MODE_CONV, Cin, dx, Cin)
     assert rel_err(nchw(dx.cpu()), x.grad) < TOL
 
 

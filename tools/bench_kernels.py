@@ -53,18 +53,18 @@ for cins, cout, s, stride in shapes:
     bias = torch.randn(cout, device=dev)
     so = s // stride
     z = torch.empty(B, so, so, cout, device=dev)
-    wp = E.pack_weight(w, 9, cout, cin, cin, 1, cin * 9, 9)
+    wp = E.pack_weight(w, 9, cout, cin, 1, cin * 9, 9)
     flops = 2.0 * B * so * so * cout * cin * 9
     tag = f"cin{'+'.join(map(str, cins))} cout{cout} {s}x{s} s{stride}"
     if which in ("all", "fwd"):
         tot_f += timeit(lambda: E.igemm([n.src() for n in srcs], wp, bias, B, s, s, so, so, 3, 3, stride, 1, E.MODE_CONV,
-                                        cout, cin, z, cout), flops, "fwd   " + tag)
+                                        cout, z, cout), flops, "fwd   " + tag)
     if cin >= 64 and which in ("all", "dgrad"):
-        wd = E.pack_weight(w, 9, cin, cout, cout, 1, 9, cin * 9)
+        wd = E.pack_weight(w, 9, cin, cout, 1, 9, cin * 9)
         dx = torch.empty(B, s, s, cin, device=dev)
         mo = E.MORDER_PARITY if stride == 2 else E.MORDER_LINEAR
         tot_d += timeit(lambda: E.igemm([E.plain_src(z, cout)], wd, None, B, so, so, s, s, 3, 3, stride, 1, E.MODE_TCONV,
-                                        cin, cout, dx, cin, morder=mo), flops, "dgrad " + tag)
+                                        cin, dx, cin, morder=mo), flops, "dgrad " + tag)
     if which in ("all", "wgrad"):
         dW = torch.empty(cout, cin, 3, 3, device=dev)
         tot_w += timeit(lambda: E.wgrad(E.plain_src(z, cout), [n.src() for n in srcs], dW, B, so, so, s, s, 3, 3, stride,
