@@ -80,6 +80,15 @@ __device__ __forceinline__ float4 src_transform4(float4 v, const MsegSrc& s, int
   return v;
 }
 
+// XCD-aware workgroup order (MI355X: 8 XCDs, each with a private L2; hardware deals consecutive workgroup ids
+// round-robin over the XCDs).  Maps the hardware id to a logical id such that each XCD works on one CONTIGUOUS range of
+// logical ids: workgroups that share an operand slab (neighbouring logical ids) then share an L2.  Bijective for any
+// grid size; affects speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_logical_id(unsigned hw_id, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = hw_id & 7u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (hw_id >> 3);
+}
+
 // max(v, lo) as ONE VALU instruction (v_med3_f32); fmaxf lowers to canonicalize + v_max.  lo = 0 -> ReLU, -FLT_MAX -> no-op
 __device__ __forceinline__ float clamp_lo(float v, float lo) {
   return __builtin_amdgcn_fmed3f(v, lo, __builtin_inff());

@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 
   const int M = p.NB * p.Ho * p.Wo;
   const int ntiles_n = (p.Ngemm + BN - 1) / BN;
-  // consecutive workgroups share the A slab (same M tile, different N tile) -> L2 reuse
-  const int tile_m = blockIdx.x / ntiles_n;
-  const int tile_n = blockIdx.x - tile_m * ntiles_n;
+  // consecutive logical ids share the A slab (same M tile, different N tile) and are placed on one XCD -> L2 reuse
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile_m = lid / ntiles_n;
+  const int tile_n = lid - tile_m * ntiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int T = p.KH * p.KW;
@@ -413,8 +414,9 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int M = p.NB * p.Ho * p.Wo;
   const int ntiles_n = (p.Ngemm + BN - 1) / BN;
-  const int tile_m = blockIdx.x / ntiles_n;
-  const int tile_n = blockIdx.x - tile_m * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);   // N tiles of one M tile -> same XCD (share the A slab)
+  const int tile_m = lid / ntiles_n;
+  const int tile_n = lid - tile_m * ntiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int T = p.KH * p.KW;
   const int srow = tid >> 3, scol = tid & 7;

@@ -36,9 +36,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
   const int Mch = p.P.C, Nch = p.Nch;
   const int T = p.KH * p.KW;
   const int ntiles_n = (Nch + 63) / 64;
-  const int mt = blockIdx.x / ntiles_n, nt = blockIdx.x - mt * ntiles_n;
-  const int split = blockIdx.y;
-  const int ky = blockIdx.z;
+  // 1-D grid; logical order: tile fastest, then kernel row, then split -> all workgroups that read the same pixel
+  // range (one split) are neighbours in logical order and run on one XCD (shared L2 for the P / Q slabs)
+  const int ntiles = ((Mch + 63) / 64) * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles;
+  const int ky = (lid / ntiles) % p.KH;
+  const int split = lid / (ntiles * p.KH);
+  const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
 
   const long long Ptot = (long long)p.NB * p.Hp * p.Wp;
   const long long pix_begin = (long long)split * steps_per_split * WG_PIX;
@@ -213,9 +218,14 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int 
   const int Mch = p.P.C, Nch = p.Nch;
   const int T = p.KH * p.KW;
   const int ntiles_n = (Nch + 63) / 64;
-  const int mt = blockIdx.x / ntiles_n, nt = blockIdx.x - mt * ntiles_n;
-  const int split = blockIdx.y;
-  const int ky = blockIdx.z;
+  // 1-D grid; logical order: tile fastest, then kernel row, then split -> all workgroups that read the same pixel
+  // range (one split) are neighbours in logical order and run on one XCD (shared L2 for the P / Q slabs)
+  const int ntiles = ((Mch + 63) / 64) * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles;
+  const int ky = (lid / ntiles) % p.KH;
+  const int split = lid / (ntiles * p.KH);
+  const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
 
   const int Ptot = p.NB * p.Hp * p.Wp;
   const int pix_begin = split * steps_per_split * WG_PIX;
@@ -443,7 +453,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       if (p.Q[i].act != MSEG_ACT_NONE && p.Q[i].act != MSEG_ACT_RELU) generic = true;
       if (p.Q[i].scale && p.Q[i].ss != 0) per_sample = true;
     }
-    const dim3 grid(tiles, splits, p.KH), block(256);
+    const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)p.KH), block(256);
     // fast path preconditions (see wgrad_fast_kernel)
     const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
     bool fast = !per_sample && Ptot64 * p.P.C * 4 < 0x80000000LL && (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;

@@ -110,6 +110,38 @@ class KernelTimer:
 _timer = None
 
 
+def _tr_of(s):
+    if s.act == ACT["none"] and not s.scale:
+        return 0
+    return 1 if s.act in (ACT["none"], ACT["relu"]) else 2
+
+
+def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm):
+    """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
+    appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
+    bn = 128 if Ngemm > 64 else 64
+    per_sample = any(s.scale and s.ss != 0 for s in srcs)
+    generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in srcs)
+    fast = (mode == MODE_CONV or stride == 1)
+    fast = fast and all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs) and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31
+    fast = fast and (len(srcs) == 1 or srcs[0].C % 32 == 0)
+    if fast:
+        tr = max(_tr_of(s) for s in srcs)
+        tr = 0 if tr == 0 else (2 if generic else 1)
+        return "igemm_fast_kernel<128, %d, %d, %s>" % (bn, tr, "true" if (per_sample and tr) else "false")
+    return "igemm_kernel<128, %d, %s, %s>" % (bn, "true" if per_sample else "false", "true" if generic else "false")
+
+
+def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW):
+    per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
+    generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
+    fast = (not per_sample) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
+    fast = fast and (len(Qs) == 1 or Qs[0].C % 64 == 0)
+    if fast:
+        return "wgrad_fast_kernel<%d, %d, %d>" % (KW, _tr_of(P), max(_tr_of(s) for s in Qs))
+    return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
+
+
 def set_kernel_timer(t):
     global _timer
     _timer = t
@@ -170,7 +202,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
-    e0, e1 = _timer.bracket("igemm_kernel<128,128>" if Ngemm > 64 else "igemm_kernel<128,64>", flops)
+    e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm), flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
@@ -197,7 +229,7 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
         check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
         return
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
-    e0, e1 = _timer.bracket("wgrad_kernel<%d>" % KW, flops)
+    e0, e1 = _timer.bracket(_wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW), flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
