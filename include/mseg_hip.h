@@ -130,6 +130,13 @@ int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act
                   const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, float* dbias,
                   void* ws, void* stream);
 
+/* MaxPool2d(2, 2) of a norm-on-load operand (pool_method = 'max': unets.py:306-307,363-364).  Forward writes the plain
+ * pooled tensor [N][H/2][W/2][C]; backward routes gout to the first maximum of each window (torch's rule) and writes
+ * (or accumulates into) gin = dL/d(normalised operand), [N][H][W][C].                                          */
+int mseg_maxpool2x2_fwd(const MsegSrc* src, int N, int H, int W, float* out, void* stream);
+int mseg_maxpool2x2_bwd(const MsegSrc* src, int N, int H, int W, const float* gout, float* gin, int accumulate,
+                        void* stream);
+
 /* ---- 1x1 output heads (unets.py:347,460-461) ------------------------------------------------------------
  * out (NCHW, [N][Co][HW]) = W[Co][C] . norm-on-load(src) + b ; Co <= 4.                                      */
 int mseg_head_fwd(const MsegSrc* src, int N, int HW, const float* w, const float* b, int Co, float* out_nchw,

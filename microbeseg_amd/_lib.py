@@ -60,6 +60,8 @@ SIGNATURES = {
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "mseg_norm_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mseg_maxpool2x2_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P]),
+    "mseg_maxpool2x2_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P, _I, _P]),
     "mseg_head_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _P, _I, _P, _P]),
     "mseg_head_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "mseg_head_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _I, _P, _P, _P, _P, _P, _P]),

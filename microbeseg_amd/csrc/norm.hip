@@ -350,3 +350,87 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
   }
   return MSEG_OK;
 }
+
+// ---- MaxPool2d(kernel 2, stride 2) on a norm-on-load operand (pool_method='max': src/utils/unets.py:306-307,363-364)
+// forward: out[n][y][x][c] = max over the 2x2 window of act(z)*scale+shift   (plain NHWC tensor, no further transform)
+// backward: the gradient goes to the FIRST maximum of the window in row-major order (torch's MaxPool2d rule).
+__global__ void maxpool_fwd_kernel(const MsegSrc s, int N, int H, int W, float* __restrict__ out) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = s.C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float4 best;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t pix = ((size_t)n * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1);
+      float4 v = *reinterpret_cast<const float4*>(s.ptr + pix * s.C + c);
+      v = src_transform4(v, s, n, c);
+      if (k == 0) best = v;
+      else { best.x = v.x > best.x ? v.x : best.x; best.y = v.y > best.y ? v.y : best.y;
+             best.z = v.z > best.z ? v.z : best.z; best.w = v.w > best.w ? v.w : best.w; }
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = best;
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const MsegSrc s, int N, int H, int W, const float* __restrict__ gout,
+                                   float* __restrict__ gin, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = s.C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float4 v[4];
+    size_t off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t pix = ((size_t)n * H + 2 * y + (k >> 1)) * W + 2 * x + (k & 1);
+      off[k] = pix * s.C + c;
+      v[k] = src_transform4(*reinterpret_cast<const float4*>(s.ptr + off[k]), s, n, c);
+    }
+    const float4 g = *reinterpret_cast<const float4*>(gout + i * 4);
+    int ax = 0, ay = 0, az = 0, aw = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      if (v[k].x > v[ax].x) ax = k;
+      if (v[k].y > v[ay].y) ay = k;
+      if (v[k].z > v[az].z) az = k;
+      if (v[k].w > v[aw].w) aw = k;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 o = make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f);
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(gin + off[k]);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(gin + off[k]) = o;
+    }
+  }
+}
+
+extern "C" int mseg_maxpool2x2_fwd(const MsegSrc* src, int N, int H, int W, float* out, void* stream) {
+  if (!src || !src->ptr || !out || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (src->C & 3)) return MSEG_EINVAL;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (src->C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblocks(total, 8192u)), dim3(256), 0, (hipStream_t)stream, *src, N, H, W, out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_maxpool2x2_bwd(const MsegSrc* src, int N, int H, int W, const float* gout, float* gin,
+                                   int accumulate, void* stream) {
+  if (!src || !src->ptr || !gout || !gin || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (src->C & 3))
+    return MSEG_EINVAL;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (src->C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks(total, 8192u)), dim3(256), 0, (hipStream_t)stream, *src, N, H, W,
+                     gout, gin, accumulate);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -318,7 +318,7 @@ class NetSpec:
         out = []
         for e in self.enc:
             out += [e["c1"], e["c2"]]
-            if e["pool"] is not None:
+            if e["pool"] is not None and e["pool"] != "max":
                 out.append(e["pool"])
         for d in self.decoders:
             for lv in d["levels"]:
@@ -392,6 +392,25 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
     return node
 
 
+class _MaxPoolMarker:
+    kind = "maxpool"
+
+
+def _run_maxpool(src_node, tape):
+    """nn.MaxPool2d(2, 2) on the normalised operand; the pooled tensor is stored plain (no pending transform)."""
+    lib = _lib.load()
+    N, H, W, Cc = src_node.N, src_node.H, src_node.W, src_node.C
+    out = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.float32, device=src_node.z.device)
+    s = src_node.src()
+    check(lib.mseg_maxpool2x2_fwd(C.byref(s), N, H, W, out.data_ptr(), _stream()), "maxpool_fwd")
+    node = Node(out, N, H // 2, W // 2, Cc)
+    node.layer = _MaxPoolMarker
+    node.inputs = (src_node,)
+    if tape is not None:
+        tape.nodes.append(node)
+    return node
+
+
 def forward(spec, x, training, keep_tape, ws):
     """x: (N, ch_in, H, W) fp32 CUDA tensor.  Returns (list of NCHW outputs, Tape|None)."""
     lib = _lib.load()
@@ -400,8 +419,6 @@ def forward(spec, x, training, keep_tape, ws):
     div = 2 ** (nlev - 1)
     if H % div or W % div:
         raise RuntimeError(f"input {H}x{W} is not divisible by {div}")
-    if spec.pool_method != "conv":
-        raise NotImplementedError("pool_method='max' is not implemented on the HIP path yet")
     dev = x.device
     c4 = _pad4(cin)
     x4 = torch.zeros((N, H, W, c4), dtype=torch.float32, device=dev)
@@ -418,7 +435,10 @@ def forward(spec, x, training, keep_tape, ws):
         cur = _run_conv(e["c2"], [cur], training, ws, tape)
         if e["pool"] is not None:
             skips.append(cur)
-            cur = _run_conv(e["pool"], [cur], training, ws, tape)
+            if e["pool"] == "max":
+                cur = _run_maxpool(cur, tape)
+            else:
+                cur = _run_conv(e["pool"], [cur], training, ws, tape)
     bottom = cur
     outs = []
     for d in spec.decoders:
@@ -476,11 +496,18 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
 
     for node in reversed(tape.nodes):
         sp = node.layer
-        conv = sp.conv
         gy = node.grad
         node.grad = None
         if gy is None:
             raise RuntimeError("internal: node without gradient")
+        if sp is _MaxPoolMarker:
+            i0 = node.inputs[0]
+            tgt, acc = _accumulate_target(i0, None)
+            s = i0.src()
+            check(lib.mseg_maxpool2x2_bwd(C.byref(s), i0.N, i0.H, i0.W, gy.data_ptr(), tgt.data_ptr(), acc, _stream()),
+                  "maxpool_bwd")
+            continue
+        conv = sp.conv
         nm = sp.norm_mod
         has_affine = sp.norm in (NORM["bn"], NORM["gn"])
         dgamma = torch.empty_like(nm.weight) if has_affine else None

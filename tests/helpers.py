@@ -14,7 +14,14 @@ VARIANTS = {
     "U_in_elu_8_16": ("U", "elu", "in", (8, 16), 3, "boundary"),
     "DU_gn_leakyrelu_8_32": ("DU", "leakyrelu", "gn", (8, 32), 1, "distance"),
     "U_bn_mish_8_32": ("U", "mish", "bn", (8, 32), 3, "boundary"),
+    "DU_bn_leakyrelu_max_8_32": ("DU", "leakyrelu", "bn", (8, 32), 1, "distance", "max"),
 }
+
+
+def variant(name):
+    """-> (unet_type, act, norm, filters, ch_out, label_type, pool_method)"""
+    v = VARIANTS[name]
+    return v if len(v) == 7 else v + ("conv",)
 
 
 def load_npz(name):

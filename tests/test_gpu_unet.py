@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from
+from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from, variant
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -24,8 +24,8 @@ def dev():
 
 def _build(name, dev, sd):
     from microbeseg_amd.utils.unets import build_unet
-    ut, act, norm, filters, ch_out, label_type = VARIANTS[name]
-    net = build_unet(ut, act, "conv", norm, dev, 1, ch_out=ch_out, filters=filters)
+    ut, act, norm, filters, ch_out, label_type, pool = variant(name)
+    net = build_unet(ut, act, pool, norm, dev, 1, ch_out=ch_out, filters=filters)
     net.load_state_dict(sd)
     return net
 
@@ -46,7 +46,7 @@ def _loss(net, fx, label_type, dev, sfx=""):
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_net_matches_reference_fixture(name, dev):
-    label_type = VARIANTS[name][5]
+    label_type = variant(name)[5]
     fx = load_npz(f"unet_{name}.npz")
     net = _build(name, dev, state_from(fx))
     net.eval()
@@ -73,7 +73,7 @@ def test_net_matches_reference_fixture(name, dev):
 
 
 def _traj(fxname, name, make_opt, steps, dev, tol_w):
-    label_type = VARIANTS[name][5]
+    label_type = variant(name)[5]
     fx = load_npz(fxname)
     net = _build(name, dev, state_from(fx))
     net.train()

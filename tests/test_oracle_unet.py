@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from
+from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from, variant
 from oracle import unet_ref
 
 TOL = 1e-5  # same torch build, same ops -> expected bit-equal; tolerance only guards thread-count effects
@@ -20,18 +20,19 @@ def _loss(outs, fx, label_type, suffix=""):
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_forward_backward_matches_reference(name):
-    ut, act, norm, filters, ch_out, label_type = VARIANTS[name]
+    ut, act, norm, filters, ch_out, label_type, pool = variant(name)
     fx = load_npz(f"unet_{name}.npz")
     sd = state_from(fx)
     x = torch.from_numpy(fx["x"])
     with torch.no_grad():
-        outs = unet_ref.unet_forward(sd, x, ut, act, norm, filters, training=False)
+        outs = unet_ref.unet_forward(sd, x, ut, act, norm, filters, pool_method=pool, training=False)
     outs = outs if isinstance(outs, tuple) else (outs,)
     for i, o in enumerate(outs):
         assert rel_err(o, fx[f"eval_out{i}"]) < TOL
     params = {k: v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()
               for k, v in sd.items()}
-    outs = unet_ref.unet_forward(params, x, ut, act, norm, filters, training=True, update_running_stats=True)
+    outs = unet_ref.unet_forward(params, x, ut, act, norm, filters, pool_method=pool, training=True,
+                                 update_running_stats=True)
     outs_t = outs if isinstance(outs, tuple) else (outs,)
     for i, o in enumerate(outs_t):
         assert rel_err(o.detach(), fx[f"train_out{i}"]) < TOL

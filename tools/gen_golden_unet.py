@@ -30,6 +30,7 @@ VARIANTS = [
     ("U_in_elu_8_16", "U", "elu", "in", (8, 16), 3, "boundary"),
     ("DU_gn_leakyrelu_8_32", "DU", "leakyrelu", "gn", (8, 32), 1, "distance"),
     ("U_bn_mish_8_32", "U", "mish", "bn", (8, 32), 3, "boundary"),
+    ("DU_bn_leakyrelu_max_8_32", "DU", "leakyrelu", "bn", (8, 32), 1, "distance", "max"),
 ]
 
 
@@ -77,9 +78,9 @@ def loss_of(net, crit, batch, label_type):
     return crit(out, l1), (out,)
 
 
-def fwd_bwd_fixture(name, ut, act, norm, filters, ch_out, label_type, seed):
+def fwd_bwd_fixture(name, ut, act, norm, filters, ch_out, label_type, pool="conv", seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
-    net = build_unet(ut, act, "conv", norm, "cpu", 1, ch_out=ch_out, filters=filters)
+    net = build_unet(ut, act, pool, norm, "cpu", 1, ch_out=ch_out, filters=filters)
     sd0 = seeded_state(net, rng)
     batch = make_batch(rng, 2, 32, label_type)
     crit = get_loss("smooth_l1" if label_type == "distance" else "ce_dice", label_type)
