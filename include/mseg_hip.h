@@ -120,7 +120,11 @@ int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C
 size_t mseg_norm_workspace_bytes(int N, int HW, int C);
 int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
                     const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
-                    float* running_mean, float* running_var, float momentum, void* ws, void* stream);
+                    float* running_mean, float* running_var, float momentum, float* act_out, void* ws, void* stream);
+/* act_out (nullable): also store a = act(z).  Used for the expensive activations (mish / elu / leakyrelu): consumers then
+ * read `a` with MSEG_ACT_NONE instead of re-evaluating the activation for each of the 9 taps in their K-loops.
+ * mseg_activation: a = act(z) alone (eval-mode BatchNorm has no statistics pass).                              */
+int mseg_activation(const float* z, int N, int HW, int C, int act, float* act_out, void* stream);
 /* eval-mode BatchNorm: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale */
 int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
@@ -128,7 +132,7 @@ int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
  * (NULL for IN) and optionally dbias_prev[c] = sum_p dz (the producing conv's bias gradient).               */
 int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
                   const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, float* dbias,
-                  void* ws, void* stream);
+                  const float* act_in /* nullable: a = act(z) stored by the forward */, void* ws, void* stream);
 
 /* MaxPool2d(2, 2) of a norm-on-load operand (pool_method = 'max': unets.py:306-307,363-364).  Forward writes the plain
  * pooled tensor [N][H/2][W/2][C]; backward routes gout to the first maximum of each window (torch's rule) and writes
@@ -171,6 +175,12 @@ int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, 
 /* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
 int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
                            float beta1, float beta2, float eps, int step, void* stream);
+/* One Ranger update of one parameter tensor (ranger2020.py:142-206): gradient centralisation over dims 1.. (do_gc, rows =
+ * shape[0]), moments, rectified or plain-momentum update with step_lr = step_size * lr (host-side RAdam buffer,
+ * ranger2020.py:160-176), and the lookahead blend every k-th step (lookahead = 1).                              */
+int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, int rows, float beta1,
+                     float beta2, float eps, float step_lr, int rectified, int do_gc, int lookahead, float alpha,
+                     void* stream);
 
 /* ---- inference post-processing (src/inference/postprocessing.py) --------------------------------------------
  * distance_postprocessing(border, cell, th_seed, th_cell) (postprocessing.py:7-59) and

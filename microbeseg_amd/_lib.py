@@ -57,9 +57,10 @@ SIGNATURES = {
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mseg_activation": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "mseg_norm_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mseg_norm_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mseg_maxpool2x2_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P]),
     "mseg_maxpool2x2_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P, _I, _P]),
     "mseg_head_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _P, _I, _P, _P]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "mseg_ce_dice_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, C.c_double, _P, _P, _P]),
     "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _P]),
+    "mseg_ranger_step": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _F, _F, _F, _F, _I, _I, _I, _F, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),

@@ -33,14 +33,18 @@ extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
   return ((size_t)N * g.chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
 }
 
-// MODE 0: forward  sums of (a, a*a)           from z
-// MODE 1: backward sums of (gy, gy*a)         from (gy, z)
+// MODE 0: forward  sums of (a, a*a)           from z        (+ optional store of a = act(z) into `aio`)
+// MODE 1: backward sums of (gy, gy*a)         from (gy, z)  (a read from `aio` when given)
 // MODE 2: backward apply: dz = (k1*gy + k2*a + k3) * act'(z), sums of (dz)
+// MODE 3: a = act(z) only (eval-mode BatchNorm with an expensive activation: materialise it once for the consumers)
+// `aio`: for expensive activations (Mish / ELU / LeakyReLU path) the activated tensor is materialised once so that the
+// conv / wgrad K-loops do not re-evaluate transcendentals for each of the 9 taps and every output tile.
 template <int MODE>
 __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict__ z, const float* __restrict__ gy,
                                                         float* __restrict__ dz, const float* __restrict__ k1,
                                                         const float* __restrict__ k2, const float* __restrict__ k3,
-                                                        int kss, NormGeom g, int act, double* __restrict__ part) {
+                                                        int kss, NormGeom g, int act, double* __restrict__ part,
+                                                        float* __restrict__ aio) {
   __shared__ double red[256 * 8];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, n = blockIdx.y;
@@ -69,7 +73,11 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict_
       for (int r = row_begin + r0; r < row_end; r += rpi) {
         const size_t off = ((size_t)n * g.HW + r) * g.C + c;
         const float4 zv = *reinterpret_cast<const float4*>(z + off);
-        const float4 av = act_fwd4(zv, act);
+        float4 av;
+        if ((MODE == 1 || MODE == 2) && aio) av = *reinterpret_cast<const float4*>(aio + off);
+        else av = act_fwd4(zv, act);
+        if ((MODE == 0 || MODE == 3) && aio) *reinterpret_cast<float4*>(aio + off) = av;
+        if (MODE == 3) continue;
         if (MODE == 0) {
           s0[0] += av.x; s0[1] += av.y; s0[2] += av.z; s0[3] += av.w;
           s1[0] += (double)av.x * av.x; s1[1] += (double)av.y * av.y;
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict_
         }
       }
     }
+    if (MODE == 3) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       red[tid * 8 + j] = s0[j];
@@ -281,7 +290,8 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
 
 extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
                                const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
-                               float* running_mean, float* running_var, float momentum, void* ws, void* stream) {
+                               float* running_mean, float* running_var, float momentum, float* act_out, void* ws,
+                               void* stream) {
   if (!z || !scale || !shift || !mean || !rstd || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
   if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
   if (norm < 0 || norm > 2) return MSEG_EINVAL;
@@ -292,7 +302,7 @@ extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, in
   double* nc = part + (size_t)N * g.chunks * 3 * C;
   hipLaunchKernelGGL((norm_pass_kernel<0>), dim3(g.chunks, N), dim3(256), 0, st, z, (const float*)nullptr,
                      (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
-                     part);
+                     part, act_out);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -300,6 +310,16 @@ extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, in
   hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
                      st, (const double*)nc, g, norm, gamma, beta, eps, scale, shift, mean, rstd, running_mean,
                      running_var, momentum);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_activation(const float* z, int N, int HW, int C, int act, float* act_out, void* stream) {
+  if (!z || !act_out || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
+  NormGeom g = norm_geom(N, HW, C);
+  hipLaunchKernelGGL((norm_pass_kernel<3>), dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream, z,
+                     (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, g, act, (double*)nullptr, act_out);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -316,7 +336,7 @@ extern "C" int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const 
 
 extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm,
                              const float* gamma, const float* mean, const float* rstd, float* dz, float* dgamma,
-                             float* dbeta, float* dbias, void* ws, void* stream) {
+                             float* dbeta, float* dbias, const float* act_in, void* ws, void* stream) {
   if (!gy || !z || !mean || !rstd || !dz || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
   if (norm < 0 || norm > 2) return MSEG_EINVAL;
   if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
@@ -329,7 +349,8 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
   float* k3 = k2 + (size_t)N * C;
   const int kss = (norm == MSEG_NORM_BN) ? 0 : C;
   hipLaunchKernelGGL((norm_pass_kernel<1>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, (float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act, part);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act, part,
+                     const_cast<float*>(act_in));
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -339,7 +360,7 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
   MSEG_LAUNCH_CHECK();
   double* part2 = part;
   hipLaunchKernelGGL((norm_pass_kernel<2>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, dz, (const float*)k1,
-                     (const float*)k2, (const float*)k3, kss, g, act, part2);
+                     (const float*)k2, (const float*)k3, kss, g, act, part2, const_cast<float*>(act_in));
   MSEG_LAUNCH_CHECK();
   if (dbias) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C)), dim3(256), 0, st,

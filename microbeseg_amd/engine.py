@@ -35,11 +35,12 @@ def _pad4(c):
 
 class Node:
     """An activation tensor in pre-norm form plus the tables its consumers need to normalise it on load."""
-    __slots__ = ("z", "N", "H", "W", "C", "act", "norm", "scale", "shift", "ss", "mean", "rstd", "layer", "inputs",
+    __slots__ = ("z", "a", "N", "H", "W", "C", "act", "norm", "scale", "shift", "ss", "mean", "rstd", "layer", "inputs",
                  "grad")
 
     def __init__(self, z, N, H, W, C):
         self.z, self.N, self.H, self.W, self.C = z, N, H, W, C
+        self.a = None          # act(z), materialised once for the expensive activations (see norm_stats)
         self.act, self.norm = 0, None
         self.scale = self.shift = self.mean = self.rstd = None
         self.ss = 0
@@ -50,7 +51,11 @@ class Node:
         s.ptr = self.z.data_ptr()
         s.C = self.C
         if transform:
-            s.act = self.act
+            if self.a is not None:      # consumers read the stored activation: no transcendentals in their K-loops
+                s.ptr = self.a.data_ptr()
+                s.act = ACT["none"]
+            else:
+                s.act = self.act
             s.scale = _ptr(self.scale)
             s.shift = _ptr(self.shift)
             s.ss = self.ss
@@ -244,6 +249,9 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
     dev = node.z.device
     node.norm = norm
     N, HW, Cc = node.N, node.H * node.W, node.C
+    expensive = node.act not in (ACT["none"], ACT["relu"])
+    if expensive:
+        node.a = torch.empty_like(node.z)
     if norm == NORM["bn"]:
         node.ss = 0
         node.scale = torch.empty(Cc, dtype=torch.float32, device=dev)
@@ -252,6 +260,9 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
             check(lib.mseg_bn_eval_coeffs(_ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
                                           BN_EPS, Cc, node.scale.data_ptr(), node.shift.data_ptr(), _stream()),
                   "bn_eval_coeffs")
+            if expensive:
+                check(lib.mseg_activation(node.z.data_ptr(), N, HW, Cc, node.act, node.a.data_ptr(), _stream()),
+                      "activation")
             return
         node.mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         node.rstd = torch.empty(Cc, dtype=torch.float32, device=dev)
@@ -267,7 +278,7 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
     check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
                               node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
                               node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
-                              w.data_ptr(), _stream()), "norm_stats")
+                              _ptr(node.a), w.data_ptr(), _stream()), "norm_stats")
 
 
 def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):
@@ -277,7 +288,7 @@ def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):
     w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
     check(lib.mseg_norm_bwd(gy.data_ptr(), node.z.data_ptr(), N, HW, Cc, node.act, node.norm, _ptr(gamma),
                             node.mean.data_ptr(), node.rstd.data_ptr(), gy.data_ptr(), _ptr(dgamma), _ptr(dbeta),
-                            _ptr(dbias), w.data_ptr(), _stream()), "norm_bwd")
+                            _ptr(dbias), _ptr(node.a), w.data_ptr(), _stream()), "norm_bwd")
     return gy
 
 

@@ -69,6 +69,27 @@ class Ranger(Optimizer):
             slot[0], slot[1], slot[2] = step, n_sma, size
         return slot[1], slot[2]
 
+    def _fused_step(self, p, state, group, beta1, beta2):
+        """MI355X path: the whole per-tensor update is ONE HIP kernel (csrc/loss.hip: ranger_step_kernel)."""
+        from .. import _lib
+        lib = _lib.load()
+        if len(state) == 0:
+            state['step'] = 0
+            state['exp_avg'] = torch.zeros_like(p)
+            state['exp_avg_sq'] = torch.zeros_like(p)
+            state['slow_buffer'] = p.detach().clone()
+        state['step'] += 1
+        n_sma, step_size = self._rectification(state['step'], beta1, beta2)
+        g = p.grad.detach().contiguous()
+        do_gc = int(self.use_gc and g.dim() > (3 if self.gc_conv_only else 1))
+        rows = g.shape[0] if do_gc else 1
+        lookahead = int(state['step'] % group['k'] == 0)
+        _lib.check(lib.mseg_ranger_step(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(),
+                                        state['exp_avg_sq'].data_ptr(), state['slow_buffer'].data_ptr(), p.numel(),
+                                        rows, beta1, beta2, group['eps'], step_size * group['lr'],
+                                        int(n_sma > self.N_sma_threshhold), do_gc, lookahead, self.alpha,
+                                        torch.cuda.current_stream().cuda_stream), "ranger_step")
+
     @torch.no_grad()
     def step(self, closure=None):
         for group in self.param_groups:
@@ -78,8 +99,11 @@ class Ranger(Optimizer):
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError('Ranger optimizer does not support sparse gradients')
-                grad = p.grad.detach().float().clone()
                 state = self.state[p]
+                if p.is_cuda and p.dtype == torch.float32 and group['weight_decay'] == 0 and self.gc_loc:
+                    self._fused_step(p, state, group, beta1, beta2)
+                    continue
+                grad = p.grad.detach().float().clone()
                 if len(state) == 0:
                     state['step'] = 0
                     state['exp_avg'] = torch.zeros_like(p, dtype=torch.float32)
