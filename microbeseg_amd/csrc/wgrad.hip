@@ -385,6 +385,172 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int 
   }
 }
 
+// =====================================================================================================================
+// Row-halo variant for the 3x3 stride-1 convolutions whose row length is a multiple of 32 (all but the deepest level of
+// the default net): a 32-pixel K-step then lies inside ONE image row, so the three x-shifted Q slabs of a kernel row are
+// one 34-pixel slab read at row offsets 0 / 1 / 2.  Q is loaded and normalised once instead of three times, and the
+// pixel position of a step is wave-uniform (scalar registers): per staged row the K-loop spends one add and one range
+// check on addressing.  LDS per stage: (32 + 34) x 68 floats.
+template <int PTR, int QTR>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int splits, int steps_per_split) {
+  constexpr int QROWS = WG_PIX + 2;
+  constexpr int STAGE = (WG_PIX + QROWS) * WG_LDS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Mch = p.P.C, Nch = p.Nch;
+  const int ntiles_n = (Nch + 63) / 64;
+  const int ntiles = ((Mch + 63) / 64) * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles;
+  const int ky = (lid / ntiles) % 3;
+  const int split = lid / (ntiles * 3);
+  const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
+
+  const int Ptot = p.NB * p.Hp * p.Wp;
+  const int pix_begin = split * steps_per_split * WG_PIX;
+  int pix_end = pix_begin + steps_per_split * WG_PIX;
+  if (pix_end > Ptot) pix_end = Ptot;
+  const int nsteps = pix_end > pix_begin ? (pix_end - pix_begin) / WG_PIX : 0;   // Ptot % 32 == 0 here
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int spx = tid >> 4, sc4 = tid & 15;
+  const int mc = mt * 64 + sc4 * 4;
+  const int qc = nt * 64 + sc4 * 4;
+  const bool q1 = (p.nq > 1) && (nt * 64 >= p.Q[0].C);
+  const MsegSrc& qs = q1 ? p.Q[1] : p.Q[0];
+  const bool mvalid = mc < Mch, qvalid = qc < Nch;
+  const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
+  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, Ptot * Mch * 4,
+                                                                        0x00020000);
+  const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0,
+                                                                        Ptot * qs.C * 4, 0x00020000);
+  float4 psc, psh, qsc, qsh;
+  {
+    const float* a = (PTR && p.P.scale) ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
+    const float* b = (PTR && p.P.scale) ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
+    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
+    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
+    psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
+    qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
+  }
+  const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+  const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+
+  // wave-uniform position of the NEXT step to load: image n, row py, first column px0 (px0 % 32 == 0)
+  int sn = pix_begin / (p.Hp * p.Wp);
+  int srem = pix_begin - sn * (p.Hp * p.Wp);
+  int spy = srem / p.Wp, spx0 = srem - spy * p.Wp;
+  // per-thread constants: halo rows j = spx, spx + 16 and (threads with spx < 2) 32 + spx; column j <-> qx = px0 - pad + j
+  const unsigned pv[2] = {(unsigned)spx * mC4 + (unsigned)(mvalid ? mc : 0) * 4u,
+                          (unsigned)(spx + 16) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u};
+  const int qj[3] = {spx, spx + 16, spx + 32};
+  const bool third = spx < 2;
+
+  float4 rp[2], rq[3];
+  float pm, qm[3];
+
+  auto issue = [&](int step) {
+    const bool live = step < nsteps;                                             // scalar
+    const unsigned psoff = (unsigned)(pix_begin + step * WG_PIX) * mC4;          // scalar, P rows are consecutive pixels
+    const bool pok = live & mvalid;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv[i] : OOB, psoff, 0));
+      rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (PTR) pm = pok ? 1.f : 0.f;
+    const int qy = spy + ky - p.pad;                                             // scalar
+    const bool yok = live & (qy >= 0) & (qy < p.Hq);
+    const int qx0 = spx0 - p.pad;                                                // scalar
+    const unsigned sb = (unsigned)(((sn * p.Hq + qy) * p.Wq + qx0) * (int)qC4) + qcl4;   // scalar, wraps by design
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || third) {
+        const int qx = qx0 + qj[i];
+        const bool ok = yok & qvalid & (qx >= 0) & (qx < p.Wq);
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsq, ok ? sb + (unsigned)qj[i] * qC4 : OOB, 0, 0));
+        rq[i] = make_float4(q[0], q[1], q[2], q[3]);
+        if (QTR) qm[i] = ok ? 1.f : 0.f;
+      }
+    }
+    // advance the scalar position by one step (rows are multiples of 32 pixels long)
+    spx0 += WG_PIX;
+    if (spx0 >= p.Wp) { spx0 = 0; spy += 1; if (spy >= p.Hp) { spy = 0; sn += 1; } }
+  };
+
+  auto xf = [&](float4 v, const float4& sc, const float4& sh, float m, int act, float lo, int tr) -> float4 {
+    if (tr == 0) return v;
+    if (tr == 2) v = act_fwd4(v, act);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+
+  auto commit = [&](float* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(stage + (spx + 16 * i) * WG_LDS + sc4 * 4) =
+          xf(rp[i], psc, psh, PTR ? pm : 1.f, p.P.act, plo, PTR);
+    float* qst = stage + WG_PIX * WG_LDS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || third)
+        *reinterpret_cast<float4*>(qst + qj[i] * WG_LDS + sc4 * 4) =
+            xf(rq[i], qsc, qsh, QTR ? qm[i] : 1.f, qs.act, qlo, QTR);
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    commit(lds);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    issue(step + 1);
+    const float* st = lds + buf * STAGE;
+    const float* qst = st + WG_PIX * WG_LDS;
+    float a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WG_LDS + wm * 32 + li];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float b = qst[(2 * kk + lh + kx) * WG_LDS + wn * 32 + li];   // column px + kx - pad of the halo slab
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
+      }
+    }
+    commit(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int n = nt * 64 + wn * 32 + li;
+  if (n < Nch) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int t = ky * 3 + kx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < Mch) p.ws[(((size_t)split * 9 + t) * Mch + m) * Nch + n] = acc[kx][r];
+      }
+    }
+  }
+}
+
 // dst[(m*Nst + n)*T + t] = sum_s ws[((s*T + t)*Mch + m)*Nch + n]   (fixed order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dst, int splits, int T,
                                     int Mch, int Nch, int Nst) {
@@ -476,6 +642,15 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       const int ptr = tr_of(p.P);
       int qtr = 0;
       for (int i = 0; i < p.nq; ++i) { const int v = tr_of(p.Q[i]); if (v > qtr) qtr = v; }
+      const bool halo = p.KH == 3 && p.KW == 3 && p.stride == 1 && (p.Wp % WG_PIX) == 0 && p.Hq == p.Hp && p.Wq == p.Wp;
+      if (halo) {
+#define MSEG_WH(P_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<P_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WH_Q(P_) do { if (qtr == 0) MSEG_WH(P_, 0); else if (qtr == 1) MSEG_WH(P_, 1); else MSEG_WH(P_, 2); } while (0)
+        if (ptr == 0) MSEG_WH_Q(0); else if (ptr == 1) MSEG_WH_Q(1); else MSEG_WH_Q(2);
+#undef MSEG_WH_Q
+#undef MSEG_WH
+        MSEG_LAUNCH_CHECK();
+      } else {
 #define MSEG_WF(KW_, P_, Q_) hipLaunchKernelGGL((wgrad_fast_kernel<KW_, P_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_WF_Q(KW_, P_) do { if (qtr == 0) MSEG_WF(KW_, P_, 0); else if (qtr == 1) MSEG_WF(KW_, P_, 1); else MSEG_WF(KW_, P_, 2); } while (0)
 #define MSEG_WF_P(KW_) do { if (ptr == 0) MSEG_WF_Q(KW_, 0); else if (ptr == 1) MSEG_WF_Q(KW_, 1); else MSEG_WF_Q(KW_, 2); } while (0)
@@ -483,6 +658,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
 #undef MSEG_WF_P
 #undef MSEG_WF_Q
 #undef MSEG_WF
+      }
     } else {
 #define MSEG_WGRAD_LAUNCH(KW_, GA_, PS_) \
   hipLaunchKernelGGL((wgrad_kernel<KW_, GA_, PS_>), grid, block, 0, st, p, splits, sps)

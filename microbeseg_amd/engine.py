@@ -137,11 +137,13 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm):
     return "igemm_kernel<128, %d, %s, %s>" % (bn, "true" if per_sample else "false", "true" if generic else "false")
 
 
-def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW):
+def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
     fast = (not per_sample) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
     fast = fast and (len(Qs) == 1 or Qs[0].C % 64 == 0)
+    if fast and KW == 3 and stride == 1 and Wp % 32 == 0 and Hq == Hp and Wq == Wp:
+        return "wgrad_halo_kernel<%d, %d>" % (_tr_of(P), max(_tr_of(s) for s in Qs))
     if fast:
         return "wgrad_fast_kernel<%d, %d, %d>" % (KW, _tr_of(P), max(_tr_of(s) for s in Qs))
     return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
@@ -234,7 +236,7 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
         check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
         return
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
-    e0, e1 = _timer.bracket(_wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW), flops)
+    e0, e1 = _timer.bracket(_wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride), flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
