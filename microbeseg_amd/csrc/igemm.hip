@@ -94,10 +94,10 @@ __device__ __forceinline__ bool tap_coord(const TapGeom& g, const RowInfo& r, in
 }
 
 // ---- shared epilogue ---------------------------------------------------------------------------------------------
-template <int BM, int BN, typename AccT>
+template <typename Cfg, typename AccT>
 __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, int m0, int n0, int wm, int wn,
-                                               int lane, int M) {
-  using Cfg = IgemmCfg<BM, BN>;
+                                               int lane, int M, int tw_log2 = -1, int img2 = 0, int oy0 = 0,
+                                               int ox0 = 0) {
   const int li = lane & 31, lh = lane >> 5;
   // The epilogue-only fields are re-read from kernarg memory here (opaque pointer) so that they do not occupy
   // SGPRs during the K-loop (the whole descriptor live = SGPR spills reloaded every iteration).
@@ -131,7 +131,12 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + wm * Cfg::TM + a * 32 + row;
+        int m = m0 + wm * Cfg::TM + a * 32 + row;
+        if (tw_log2 >= 0) {   // 2-D pixel tile of the halo kernel: rows below the image are dropped
+          const int i = wm * Cfg::TM + a * 32 + row;
+          const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
+          m = oy < e_Ho ? (img2 * e_Ho + oy) * e_Wo + ox : M;
+        }
         if (!nvalid || m >= M) continue;
         size_t off;
         if (e_epi == MSEG_EPI_SCATTER2X2) {
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
     dbg[0] = (float)t_issue; dbg[1] = (float)t_mfma; dbg[2] = (float)t_commit; dbg[3] = (float)t_bar;
   }
 #endif
-  igemm_epilogue<BM, BN>(acc, m0, n0, wm, wn, lane, M);
+  igemm_epilogue<IgemmCfg<BM, BN>>(acc, m0, n0, wm, wn, lane, M);
 }
 
 // =====================================================================================================================
@@ -585,7 +590,217 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
     __syncthreads();
     cur ^= 1;
   }
-  igemm_epilogue<BM, BN>(acc, m0, n0, wm, wn, lane, M);
+  igemm_epilogue<IgemmCfg<BM, BN>>(acc, m0, n0, wm, wn, lane, M);
+}
+
+// =====================================================================================================================
+// Halo kernel for the 3x3 stride-1 convolutions and their data gradients (the bulk of the FLOPs).  A workgroup owns a
+// TH x TW pixel rectangle (TH * TW = 128, TW = largest power of two <= 128 dividing the row length) of one image and
+// BN output channels.  Per 32-channel chunk the (TH+2) x (TW+2) input halo is loaded, normalised and written to LDS
+// ONCE; the nine taps then read their MFMA A-fragments from shifted rows of that slab (per-lane base + wave-uniform
+// tap offset).  Compared with the gather kernels this removes 8/9 of the operand loads and of the norm-on-load VALU
+// work — which matters because the fp32 matrix op shares the SIMD with VALU (see igemm_fast_kernel).
+// LDS: double-buffered halo (2 x 390 rows) + double-buffered weight slab, 36-float rows: 148 KiB -> one workgroup per CU,
+// one wave per SIMD; all latency hiding is software pipelining (halo of chunk c+1 is fetched during chunk c).
+// A tile never spans two images, so per-sample (Group/InstanceNorm) tables need no special case.
+template <int BN>
+struct HaloCfg {
+  static constexpr int WN = (BN >= 128) ? 4 : 2;
+  static constexpr int WM = 8 / WN;
+  static constexpr int TM = 128 / WM, TN = BN / WN;
+  static constexpr int MB = TM / 32, NB = TN / 32;
+  static constexpr int BROWS = BN / 64;
+};
+
+template <int BN, int TR>
+__global__ __launch_bounds__(512) void igemm_halo_kernel(const MsegIgemm p, int tw_log2) {
+  constexpr int BM = 128;
+  // 8 waves (two per SIMD, same workgroup): 2 x 4 wave grid for BN = 128 (64 x 32 per wave), 4 x 2 for BN = 64 (32 x 32)
+  using Cfg = HaloCfg<BN>;
+  constexpr int HMAX = 390;                          // (1 + 2) x (128 + 2), the largest halo
+  constexpr int HL = (HMAX * 8 + 511) / 512;         // float4 per thread per chunk (7)
+  constexpr int ASTAGE = HMAX * LDS_STRIDE;
+  constexpr int BSTAGE = BN * LDS_STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[2 * ASTAGE + 2 * BSTAGE];
+  float* const Abuf = lds;
+  float* const Bbuf = lds + 2 * ASTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = tid >> 3, scol = tid & 7;
+  const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
+  const int HROWS = (TH + 2) * HW2;
+  const int H = p.Hi, W = p.Wi;                      // stride 1, pad 1: output and input have the same size
+  const int M = p.NB * H * W;
+  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile_m = lid / ntiles_n, tile_n = lid - tile_m * ntiles_n;
+  const int img = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - img * (tiles_x * tiles_y);
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  const bool conv = p.mode == MSEG_MODE_CONV;       // TCONV (data gradient) = the same halo with the taps mirrored
+
+  // ---- halo entries of this thread: rows hrow = srow + 32 j, channel quad scol ----------------------------------
+  int hpix[HL];
+  unsigned hvalid = 0u;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int hrow = srow + 64 * j;
+    const int hy = hrow / HW2, hx = hrow - hy * HW2;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+    hpix[j] = (img * H + iy) * W + ix;
+    hvalid |= (unsigned)ok << j;
+  }
+  // per-lane LDS row of the MFMA A rows (tile pixel -> halo coordinates of tap (0,0))
+  int abase[Cfg::MB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a) {
+    const int i = wm * Cfg::TM + a * 32 + li;
+    abase[a] = ((i >> tw_log2) * HW2 + (i & (TW - 1))) * LDS_STRIDE + lh * 4;
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0,
+                                                                        M * p.src[0].C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr), 0, M * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * 4,
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                        9 * p.Npad * p.Kpad * 4, 0x00020000);
+  unsigned wvoff[Cfg::BROWS];
+#pragma unroll
+  for (int i = 0; i < Cfg::BROWS; ++i) wvoff[i] = ((unsigned)(n0 + srow + 64 * i) * (unsigned)p.Kpad + scol * 4u) * 4u;
+
+  float4 rh[HL], rb[Cfg::BROWS], rsc, rsh;
+  unsigned hoff[HL];
+  unsigned hlive = 0u;       // validity of the halo registers currently in flight (hvalid & channel tail)
+  int ract = 0;
+  bool cur_s1 = false;
+  int off_src = -1;          // source for which hoff[] was computed
+
+  auto issue_halo = [&](int chunk) {
+    const int c = chunk * KC + scol * 4;
+    cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
+    const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
+    if ((int)cur_s1 != off_src) {                    // wave-uniform, at most twice per kernel
+      off_src = (int)cur_s1;
+      const unsigned sC4 = (unsigned)s.C * 4u;
+#pragma unroll
+      for (int j = 0; j < HL; ++j) hoff[j] = (unsigned)hpix[j] * sC4 + scol * 16u;
+    }
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u;      // scalar
+    hlive = (c < p.Cin) ? hvalid : 0u;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const bool ok = (hlive >> j) & 1u;
+      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? hoff[j] : OOB, soff, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? hoff[j] : OOB, soff, 0));
+      rh[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const unsigned cl = (c < p.Cin) ? (unsigned)(cur_s1 ? c - C0 : c) : 0u;
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
+      rsc = *reinterpret_cast<const float4*>(scp + o);
+      rsh = *reinterpret_cast<const float4*>(shp + o);
+    }
+  };
+
+  auto commit_halo = [&](float* As) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const int hrow = srow + 64 * j;
+      if (hrow < HMAX) {
+        float4 v = rh[j];
+        if (TR != 0) {
+          if (TR == 2) v = act_fwd4(v, ract);
+          else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+          const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+          v.x = (v.x * rsc.x + rsh.x) * m; v.y = (v.y * rsc.y + rsh.y) * m;
+          v.z = (v.z * rsc.z + rsh.z) * m; v.w = (v.w * rsc.w + rsh.w) * m;
+        }
+        *reinterpret_cast<float4*>(As + hrow * LDS_STRIDE + scol * 4) = v;
+      }
+    }
+  };
+
+  auto issue_b = [&](int chunk, int t) {
+    const unsigned wso = ((unsigned)t * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC) * 4u;
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i) {
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], wso, 0));
+      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto commit_b = [&](float* Bs) {
+#pragma unroll
+    for (int i = 0; i < Cfg::BROWS; ++i)
+      *reinterpret_cast<float4*>(Bs + (srow + 64 * i) * LDS_STRIDE + scol * 4) = rb[i];
+  };
+
+  issue_halo(0);
+  issue_b(0, 0);
+  commit_halo(Abuf);
+  commit_b(Bbuf);
+  __syncthreads();
+
+  int bsel = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float* As = Abuf + (chunk & 1) * ASTAGE;
+    const bool more_chunks = chunk + 1 < nchunks;
+    for (int t = 0; t < 9; ++t) {
+      if (t == 0 && more_chunks) issue_halo(chunk + 1);          // a whole chunk of MFMAs hides this fetch
+      // weights of the next K-step (the very last step re-reads its own: keeps the body branch-free)
+      const bool last = (t == 8) && !more_chunks;
+      issue_b(t == 8 ? (more_chunks ? chunk + 1 : chunk) : chunk, last ? 8 : (t == 8 ? 0 : t + 1));
+
+      const int ky = t / 3, kx = t - 3 * ky;
+      const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * LDS_STRIDE;   // scalar
+      const float* Bs = Bbuf + bsel * BSTAGE;
+#pragma unroll
+      for (int kk = 0; kk < KC / 8; ++kk) {
+        float4 af[Cfg::MB], bf[Cfg::NB];
+#pragma unroll
+        for (int a = 0; a < Cfg::MB; ++a)
+          af[a] = *reinterpret_cast<const float4*>(As + abase[a] + toff + kk * 8);
+#pragma unroll
+        for (int b = 0; b < Cfg::NB; ++b)
+          bf[b] = *reinterpret_cast<const float4*>(Bs + (wn * Cfg::TN + b * 32 + li) * LDS_STRIDE + kk * 8 + lh * 4);
+#pragma unroll
+        for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+          for (int b = 0; b < Cfg::NB; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+          }
+      }
+      commit_b(Bbuf + (bsel ^ 1) * BSTAGE);
+      if (t == 8 && more_chunks) commit_halo(Abuf + ((chunk + 1) & 1) * ASTAGE);
+      __syncthreads();
+      bsel ^= 1;
+    }
+  }
+  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M, tw_log2, img, oy0, ox0);
 }
 
 static int check_src(const MsegSrc& s) {
@@ -651,6 +866,25 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   }
   if ((long long)p.KH * p.KW * p.Npad * p.Kpad * 4 >= 0x80000000LL) fast = false;
   if (p.nsrc > 1 && (p.src[0].C % KC)) fast = false;
+  // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient)
+  if (fast && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
+      p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0) {
+    int tw_log2 = 7;
+    while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 128 dividing W
+    const int TH = 128 >> tw_log2;
+    const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
+    const long long htiles = mt * ((p.Ngemm + BNv - 1) / BNv);
+    if (htiles <= 0x7fffffffLL) {
+      const int tr = plain ? 0 : (generic ? 2 : 1);
+      const dim3 hgrid((unsigned)htiles);
+#define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, p, tw_log2)
+      if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
+      else      { if (tr == 0) MSEG_HALO(64, 0); else if (tr == 1) MSEG_HALO(64, 1); else MSEG_HALO(64, 2); }
+#undef MSEG_HALO
+      MSEG_LAUNCH_CHECK();
+      return MSEG_OK;
+    }
+  }
   if (fast) {
     const int tr = plain ? 0 : (generic ? 2 : 1);
 #define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_) \

@@ -121,7 +121,7 @@ def _tr_of(s):
     return 1 if s.act in (ACT["none"], ACT["relu"]) else 2
 
 
-def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm):
+def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False):
     """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
     appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
     bn = 128 if Ngemm > 64 else 64
@@ -130,6 +130,9 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm):
     fast = (mode == MODE_CONV or stride == 1)
     fast = fast and all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs) and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31
     fast = fast and (len(srcs) == 1 or srcs[0].C % 32 == 0)
+    if fast and halo_ok:
+        tr = max(_tr_of(s) for s in srcs)
+        return "igemm_halo_kernel<%d, %d>" % (bn, 0 if tr == 0 else (2 if generic else 1))
     if fast:
         tr = max(_tr_of(s) for s in srcs)
         tr = 0 if tr == 0 else (2 if generic else 1)
@@ -209,7 +212,10 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
-    e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm), flops)
+    e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
+                                               halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
+                                                        and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
+                                                        and Wi % 4 == 0)), flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
