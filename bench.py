@@ -125,7 +125,8 @@ def inference_metric(args, net, dev):
     from oracle import postproc_ref
     S, T = args.infer_size, args.infer_frames
     rng = np.random.Generator(np.random.PCG64(2024))
-    cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2))
+    # ~2500 cells / 2048^2 frame, semi-axes U[5,13] px -> ~15 % foreground, touching cells merge
+    cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2), rmin=5.0, rmax=13.0)
     c, b = torch.from_numpy(cell).to(dev), torch.from_numpy(border).to(dev)
     frame = (torch.rand(1, 1, S, S, device=dev) * 2 - 1)
     net.eval()

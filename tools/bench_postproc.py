@@ -9,7 +9,7 @@ from oracle import postproc_ref as R
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n_cells = int(sys.argv[2]) if len(sys.argv) > 2 else int(2500 * (H * W) / 2048 ** 2)
 rng = np.random.Generator(np.random.PCG64(2024))
-t0 = time.time(); cell, border = synth.synth_prediction_maps(rng, H, W, n_cells); print("synth %.1fs" % (time.time() - t0))
+t0 = time.time(); cell, border = synth.synth_prediction_maps(rng, H, W, n_cells, rmin=5.0, rmax=13.0); print("synth %.1fs" % (time.time() - t0))
 c, b = torch.from_numpy(cell).cuda(), torch.from_numpy(border).cuda()
 labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
 torch.cuda.synchronize()
