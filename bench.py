@@ -157,6 +157,27 @@ def inference_metric(args, net, dev):
                              "sample": "1 frame through oracle/postproc_ref.c (single thread, like scipy/skimage)"}}
 
 
+def default_workload(args):
+    return (args.batch, args.size, args.arch, args.act, args.norm, tuple(args.filters), args.optimizer) == \
+        (32, 256, "DU", "relu", "bn", (64, 1024), "adam")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed TCC-counter profile of this same command
+    (tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).
+    bench.py cannot collect PMC counters itself; the profile is part of the repo, not of the reference."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_pmc.json")))
+    if not files:
+        return {}
+    tab = json.load(open(files[-1]))
+    ent = tab.get(kernel)
+    if ent is None:
+        return {}
+    return {"traffic": int(ent["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (avg)",
+            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,6 +269,8 @@ def main():
                                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                                "avg_launch_ms": round(dom["avg_ms"], 4), "launches": dom["launches"]}
+            if default_workload(args):
+                out["roofline"].update(pmc_traffic(dom["kernel"]))
             out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "total_ms_per_step": round(v["total_ms"] / args.steps, 3),
                                   "avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] // args.steps}
                               for k, v in kernels.items()}
