@@ -128,10 +128,71 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
     }
 #pragma unroll
     for (int a = 0; a < Cfg::MB; ++a) {
+      // Affine row addressing: the 32 rows of one MFMA tile are consecutive GEMM rows, so when they lie on one image
+      // row the destination offset is base + row * step and the per-element divisions (costly VALU work that the
+      // short-K layers cannot hide) disappear.  Wave-uniform choice; the general decode below stays as the fallback.
+      const int mb = m0 + wm * Cfg::TM + a * 32;
+      bool affine = false;
+      size_t base = 0;
+      int step = 0;
+      bool tile_ok = mb < M;
+      if (tw_log2 >= 0) {
+        if (tw_log2 >= 5) {       // halo kernel, pixel tile at least 32 wide: the MFMA tile is one image-row segment
+          const int i = wm * Cfg::TM + a * 32;
+          const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
+          tile_ok = oy < e_Ho;
+          base = ((size_t)(img2 * e_Ho + oy) * e_Wo + ox) * ld + noff;
+          step = ld;
+          affine = true;
+        }
+      } else if (e_epi == MSEG_EPI_SCATTER2X2) {
+        if ((e_Wo & 31) == 0 && tile_ok) {
+          const int img = mb / (e_Ho * e_Wo);
+          const int rem = mb - img * (e_Ho * e_Wo);
+          const int oy = rem / e_Wo, ox = rem - oy * e_Wo;
+          base = (((size_t)img * (2 * e_Ho) + 2 * oy + sa) * (2 * e_Wo) + 2 * ox + sb) * e_Cq + noff;
+          step = 2 * e_Cq;
+          affine = true;
+        }
+      } else if (e_morder == MSEG_MORDER_PARITY) {
+        if (((e_Wo >> 1) & 31) == 0 && tile_ok) {
+          const RowInfo ri = decode_row(*pe, mb, M);
+          base = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
+          step = 2 * ld;
+          affine = true;
+        }
+      } else {
+        base = (size_t)mb * ld + noff;
+        step = ld;
+        affine = true;
+      }
+      if (affine) {
+        // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16
+        // memory round trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
+        if (!nvalid || !tile_ok) continue;
+        float* const d = dst + base;
+        const int rows_left = (tw_log2 >= 0) ? 32 : M - mb;      // halo tiles never straddle the end of M
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        if (accf) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < rows_left) old[r] = d[(unsigned)(row * step)];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < rows_left) d[(unsigned)(row * step)] = acc[a][b][r] + bias + old[r];
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        int m = m0 + wm * Cfg::TM + a * 32 + row;
+        int m = mb + row;
         if (tw_log2 >= 0) {   // 2-D pixel tile of the halo kernel: rows below the image are dropped
           const int i = wm * Cfg::TM + a * 32 + row;
           const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
@@ -404,8 +465,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 //   * weight rows need no per-step VALU at all (constant voffset, the step offset is the scalar soffset);
 //   * scale/shift tables are fetched once per 32-channel chunk, not once per tap;
 //   * operands without transform (all dgrad launches) are committed to LDS untouched.
-// Preconditions (checked on the host, otherwise the generic kernel above runs): CONV mode or stride-1 TCONV, every
-// operand < 2 GiB, and the concat boundary C0 a multiple of 32 (wave-uniform source selection).
+// Preconditions (checked on the host, otherwise the generic kernel above runs): CONV mode, stride-1 TCONV, or stride-2
+// TCONV in parity M-order with parity classes that are whole tiles; every operand < 2 GiB; the concat boundary C0 a
+// multiple of 32 (wave-uniform source selection).
 // TR: 0 = plain operand, 1 = none/ReLU + affine, 2 = any activation + affine.
 template <int BM, int BN, int TR, bool PER_SAMPLE>
 __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
@@ -434,7 +496,9 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
 #pragma unroll
   for (int i = 0; i < Cfg::AROWS; ++i) {
     const RowInfo r = decode_row(p, m0 + srow + 32 * i, M);
-    const int iy0 = r.oy * geom.sm - geom.dir * geom.pad, ix0 = r.ox * geom.sm - geom.dir * geom.pad;
+    // source coordinate of a live tap = (o * sm - dir * pad) >> sh  +  dir * (k >> sh): linear in the tap for every
+    // row of the tile (stride-2 TCONV: the parity M-order makes the live-tap set tile-uniform, see `taplist`)
+    const int iy0 = (r.oy * geom.sm - geom.dir * geom.pad) >> geom.sh, ix0 = (r.ox * geom.sm - geom.dir * geom.pad) >> geom.sh;
     pix0[i] = (r.n * p.Hi + iy0) * p.Wi + ix0;
     rown[i] = r.n < 0 ? 0 : r.n;
     unsigned mk = 0u;
@@ -505,7 +569,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
     }
     const unsigned cbit = (c < p.Cin) ? (1u << t) : 0u;                      // channel tail of the last chunk
     const unsigned sC4 = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * 4u;   // scalar
-    const unsigned delta = (unsigned)(geom.dir * (ky * p.Wi + kx)) * sC4;     // scalar, wraps mod 2^32 by design
+    const unsigned delta = (unsigned)(geom.dir * ((ky >> geom.sh) * p.Wi + (kx >> geom.sh))) * sC4;   // scalar, wraps by design
 #pragma unroll
     for (int i = 0; i < Cfg::AROWS; ++i) {
       const bool ok = (vmask[i] & cbit) != 0u;
@@ -546,11 +610,32 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
       *reinterpret_cast<float4*>(Bs + (srow + 32 * i) * LDS_STRIDE + scol * 4) = rb[i];
   };
 
-  // K-step iterator: chunk outer, tap inner; every tap is live for at least one row in CONV / stride-1 TCONV
-  int chunk = 0, t = 0, ky = 0, kx = 0;
-  const int KWm1 = p.KW - 1;
-  const int nsteps = nchunks * T;
-  issue(0, 0, 0, 0);
+  // K-step iterator: chunk outer, live tap inner.  Every tap is live for at least one row in CONV / stride-1 TCONV; a
+  // stride-2 TCONV tile (parity M-order, class size a multiple of BM: host-checked) has the taps whose phase matches
+  // the tile's output parity.  The live taps are kept as a packed scalar list: 8 bits per entry = t | ky << 4 | kx << 6.
+  unsigned long long taplist = 0ull, taplist_hi = 0ull;
+  int nlive = 0;
+  {
+    int py = 0, px = 0;
+    if (geom.sh) {
+      const int cls = m0 / (M >> 2);
+      py = cls >> 1; px = cls & 1;
+    }
+    for (int tt = 0; tt < T; ++tt) {
+      const int ky_ = tt / p.KW, kx_ = tt - ky_ * p.KW;
+      const bool live = (((py - geom.dir * (ky_ - geom.pad)) | (px - geom.dir * (kx_ - geom.pad))) & geom.sh) == 0;
+      if (live) {
+        const unsigned long long e = (unsigned long long)(tt | (ky_ << 4) | (kx_ << 6));
+        if (nlive < 8) taplist |= e << (8 * nlive); else taplist_hi |= e << (8 * (nlive - 8));
+        ++nlive;
+      }
+    }
+  }
+  auto tap_at = [&](int j) -> unsigned { return (unsigned)((j < 8 ? taplist >> (8 * j) : taplist_hi >> (8 * (j - 8))) & 0xffull); };
+  int chunk = 0, j = 0;
+  const int nsteps = nchunks * nlive;
+  unsigned e0 = tap_at(0);
+  issue(0, (int)(e0 & 15u), (int)((e0 >> 4) & 3u), (int)(e0 >> 6));
   commit(lds, lds + BM * LDS_STRIDE);
   __syncthreads();
   int cur = 0;
@@ -558,11 +643,11 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
   for (int step = 0; step < nsteps; ++step) {
     // prefetch the next K-step (the last iteration re-reads the current one: keeps the body branch-free)
     if (step + 1 < nsteps) {
-      const int wrap = (kx == KWm1) ? 1 : 0;
-      t += 1; kx = wrap ? 0 : kx + 1; ky += wrap;
-      if (t >= T) { t = 0; ky = 0; kx = 0; ++chunk; }
+      j += 1;
+      if (j >= nlive) { j = 0; ++chunk; }
     }
-    issue(chunk, t, ky, kx);
+    e0 = tap_at(j);
+    issue(chunk, (int)(e0 & 15u), (int)((e0 >> 4) & 3u), (int)(e0 >> 6));
 
     const float* As = lds + cur * STAGE;
     const float* Bs = As + BM * LDS_STRIDE;
@@ -858,13 +943,15 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
   const dim3 grid((unsigned)tiles), block(256);
   // fast path preconditions (see igemm_fast_kernel)
-  bool fast = (p.mode == MSEG_MODE_CONV) || (p.stride == 1);
+  bool fast = (p.mode == MSEG_MODE_CONV) || (p.stride == 1) ||
+              (p.morder == MSEG_MORDER_PARITY && (M % (4 * BMv)) == 0);   // s2 dgrad: parity-uniform tiles
   bool plain = true;
   for (int i = 0; i < p.nsrc; ++i) {
     if ((long long)p.NB * p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) fast = false;
     if (p.src[i].act != MSEG_ACT_NONE || p.src[i].scale) plain = false;
   }
   if ((long long)p.KH * p.KW * p.Npad * p.Kpad * 4 >= 0x80000000LL) fast = false;
+  if (p.KH > 4 || p.KW > 4) fast = false;                            // packed tap list: 2 bits per tap coordinate
   if (p.nsrc > 1 && (p.src[0].C % KC)) fast = false;
   // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient)
   if (fast && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&

@@ -121,13 +121,13 @@ def _tr_of(s):
     return 1 if s.act in (ACT["none"], ACT["relu"]) else 2
 
 
-def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False):
+def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False, parity_tiles=False):
     """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
     appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
     bn = 128 if Ngemm > 64 else 64
     per_sample = any(s.scale and s.ss != 0 for s in srcs)
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in srcs)
-    fast = (mode == MODE_CONV or stride == 1)
+    fast = (mode == MODE_CONV or stride == 1 or parity_tiles) and KH <= 4 and KW <= 4
     fast = fast and all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs) and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31
     fast = fast and (len(srcs) == 1 or srcs[0].C % 32 == 0)
     if fast and halo_ok:
@@ -215,7 +215,9 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
                                                halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
                                                         and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
-                                                        and Wi % 4 == 0)), flops)
+                                                        and Wi % 4 == 0),
+                                               parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)),
+                            flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
