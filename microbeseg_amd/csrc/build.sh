@@ -12,7 +12,9 @@ for s in $SRCS; do
   o=../_build/${s%.hip}.o
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+    # -pragma-unroll-threshold: the fully unrolled epilogues exceed LLVM's default 16k-instruction cap for "#pragma unroll";
+    # a loop left rolled would index the accumulator array dynamically and push it to scratch memory
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=200000 -c "$s" -o "$o" &
     pids+=($!)
   fi
 done
