@@ -685,8 +685,11 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
 // ONCE; the nine taps then read their MFMA A-fragments from shifted rows of that slab (per-lane base + wave-uniform
 // tap offset).  Compared with the gather kernels this removes 8/9 of the operand loads and of the norm-on-load VALU
 // work — which matters because the fp32 matrix op shares the SIMD with VALU (see igemm_fast_kernel).
-// LDS: double-buffered halo (2 x 390 rows) + double-buffered weight slab, 36-float rows: 148 KiB -> one workgroup per CU,
-// one wave per SIMD; all latency hiding is software pipelining (halo of chunk c+1 is fetched during chunk c).
+// LDS: ONE halo buffer (pixel tiles are at most 64 wide: (2 + 2) x (64 + 2) = 264 rows) + a double-buffered weight slab,
+// 36-float rows: 73 KiB (BN = 128) -> TWO workgroups of 8 waves per CU.  The halo of chunk c+1 is fetched into
+// registers during chunk c and written after its last tap (one extra barrier per chunk); whatever a workgroup cannot
+// overlap itself (first fetch, epilogue stores and read-modify-writes, barrier skew) is covered by the MFMAs of its
+// co-resident neighbour.
 // A tile never spans two images, so per-sample (Group/InstanceNorm) tables need no special case.
 template <int BN>
 struct HaloCfg {
@@ -698,17 +701,17 @@ struct HaloCfg {
 };
 
 template <int BN, int TR>
-__global__ __launch_bounds__(512) void igemm_halo_kernel(const MsegIgemm p, int tw_log2) {
+__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, int tw_log2) {
   constexpr int BM = 128;
   // 8 waves (two per SIMD, same workgroup): 2 x 4 wave grid for BN = 128 (64 x 32 per wave), 4 x 2 for BN = 64 (32 x 32)
   using Cfg = HaloCfg<BN>;
-  constexpr int HMAX = 390;                          // (1 + 2) x (128 + 2), the largest halo
-  constexpr int HL = (HMAX * 8 + 511) / 512;         // float4 per thread per chunk (7)
+  constexpr int HMAX = 264;                          // (2 + 2) x (64 + 2), the largest halo (tw_log2 <= 6)
+  constexpr int HL = (HMAX * 8 + 511) / 512;         // float4 per thread per chunk (5)
   constexpr int ASTAGE = HMAX * LDS_STRIDE;
   constexpr int BSTAGE = BN * LDS_STRIDE;
-  __shared__ __attribute__((aligned(16))) float lds[2 * ASTAGE + 2 * BSTAGE];
+  __shared__ __attribute__((aligned(16))) float lds[ASTAGE + 2 * BSTAGE];
   float* const Abuf = lds;
-  float* const Bbuf = lds + 2 * ASTAGE;
+  float* const Bbuf = lds + ASTAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const MsegIgemm p, int 
 
   int bsel = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float* As = Abuf + (chunk & 1) * ASTAGE;
+    const float* As = Abuf;
     const bool more_chunks = chunk + 1 < nchunks;
     for (int t = 0; t < 9; ++t) {
       if (t == 0 && more_chunks) issue_halo(chunk + 1);          // a whole chunk of MFMAs hides this fetch
@@ -880,7 +883,10 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const MsegIgemm p, int 
           }
       }
       commit_b(Bbuf + (bsel ^ 1) * BSTAGE);
-      if (t == 8 && more_chunks) commit_halo(Abuf + ((chunk + 1) & 1) * ASTAGE);
+      if (t == 8 && more_chunks) {
+        __syncthreads();                 // every wave is done reading this chunk's halo
+        commit_halo(Abuf);
+      }
       __syncthreads();
       bsel ^= 1;
     }
@@ -956,8 +962,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient)
   if (fast && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
       p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0) {
-    int tw_log2 = 7;
-    while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 128 dividing W
+    int tw_log2 = 6;
+    while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 64 dividing W
     const int TH = 128 >> tw_log2;
     const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
     const long long htiles = mt * ((p.Ngemm + BNv - 1) / BNv);
