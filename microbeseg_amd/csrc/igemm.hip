@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
 
 // =====================================================================================================================
 // Halo kernel for the 3x3 stride-1 convolutions and their data gradients (the bulk of the FLOPs).  A workgroup owns a
-// TH x TW pixel rectangle (TH * TW = 128, TW = largest power of two <= 128 dividing the row length) of one image and
+// TH x TW pixel rectangle (TH * TW = 128, TW = largest power of two <= 64 dividing the row length) of one image and
 // BN output channels.  Per 32-channel chunk the (TH+2) x (TW+2) input halo is loaded, normalised and written to LDS
 // ONCE; the nine taps then read their MFMA A-fragments from shifted rows of that slab (per-lane base + wave-uniform
 // tap offset).  Compared with the gather kernels this removes 8/9 of the operand loads and of the norm-on-load VALU
@@ -774,29 +774,24 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   for (int i = 0; i < Cfg::BROWS; ++i) wvoff[i] = ((unsigned)(n0 + srow + 64 * i) * (unsigned)p.Kpad + scol * 4u) * 4u;
 
   float4 rh[HL], rb[Cfg::BROWS], rsc, rsh;
-  unsigned hoff[HL];
   unsigned hlive = 0u;       // validity of the halo registers currently in flight (hvalid & channel tail)
   int ract = 0;
   bool cur_s1 = false;
-  int off_src = -1;          // source for which hoff[] was computed
 
   auto issue_halo = [&](int chunk) {
     const int c = chunk * KC + scol * 4;
     cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
     const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
-    if ((int)cur_s1 != off_src) {                    // wave-uniform, at most twice per kernel
-      off_src = (int)cur_s1;
-      const unsigned sC4 = (unsigned)s.C * 4u;
-#pragma unroll
-      for (int j = 0; j < HL; ++j) hoff[j] = (unsigned)hpix[j] * sC4 + scol * 16u;
-    }
-    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u;      // scalar
+    const unsigned sC4 = (unsigned)s.C * 4u;                                     // scalar
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u + scol * 16u;
     hlive = (c < p.Cin) ? hvalid : 0u;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       const bool ok = (hlive >> j) & 1u;
-      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? hoff[j] : OOB, soff, 0))
-                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, ok ? hoff[j] : OOB, soff, 0));
+      const unsigned vo = ok ? (unsigned)hpix[j] * sC4 + soff : OOB;   // one v_mad per load, once per chunk: keeps the
+                                                                       // kernel within 128 VGPRs (4 waves per SIMD)
+      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
       rh[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
     if (TR != 0) {
