@@ -16,10 +16,16 @@ struct NormGeom {
 static NormGeom norm_geom(int N, int HW, int C) {
   NormGeom g;
   g.N = N; g.HW = HW; g.C = C;
-  int maxc = 2048 / (N > 0 ? N : 1);
-  if (maxc < 1) maxc = 1;
-  int chunks = HW / 512;
-  if (chunks > maxc) chunks = maxc;
+  // one workgroup per (chunk of rows, sample); aim at >= 4096 workgroups (16 per CU) with at least 16 rows per row slot
+  // of a workgroup (256 threads = rpi rows x C/4 channel quads), so that deep levels (few pixels, many channels) still
+  // fill the chip and level 0 keeps long streaming loops
+  const int C4 = C >> 2;
+  const int CW = C4 < 256 ? (C4 > 0 ? C4 : 1) : 256;
+  const int rpi = 256 / CW;
+  const int min_rows = 16 * rpi;
+  int want = (4096 + N - 1) / (N > 0 ? N : 1);
+  int chunks = HW / min_rows;
+  if (chunks > want) chunks = want;
   if (chunks < 1) chunks = 1;
   g.rows_per_chunk = (HW + chunks - 1) / chunks;
   g.chunks = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
@@ -70,30 +76,44 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict_
         a2 = *reinterpret_cast<const float4*>(k2 + (size_t)n * kss + c);
         a3 = *reinterpret_cast<const float4*>(k3 + (size_t)n * kss + c);
       }
-      for (int r = row_begin + r0; r < row_end; r += rpi) {
-        const size_t off = ((size_t)n * g.HW + r) * g.C + c;
-        const float4 zv = *reinterpret_cast<const float4*>(z + off);
-        float4 av;
-        if ((MODE == 1 || MODE == 2) && aio) av = *reinterpret_cast<const float4*>(aio + off);
-        else av = act_fwd4(zv, act);
-        if ((MODE == 0 || MODE == 3) && aio) *reinterpret_cast<float4*>(aio + off) = av;
-        if (MODE == 3) continue;
-        if (MODE == 0) {
-          s0[0] += av.x; s0[1] += av.y; s0[2] += av.z; s0[3] += av.w;
-          s1[0] += (double)av.x * av.x; s1[1] += (double)av.y * av.y;
-          s1[2] += (double)av.z * av.z; s1[3] += (double)av.w * av.w;
-        } else {
-          const float4 gv = *reinterpret_cast<const float4*>(gy + off);
-          if (MODE == 1) {
-            s0[0] += gv.x; s0[1] += gv.y; s0[2] += gv.z; s0[3] += gv.w;
-            s1[0] += (double)gv.x * av.x; s1[1] += (double)gv.y * av.y;
-            s1[2] += (double)gv.z * av.z; s1[3] += (double)gv.w * av.w;
+      // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
+      // one load pair per trip left the pass latency-bound at ~3 TB/s
+      constexpr int U = 4;
+      for (int r = row_begin + r0; r < row_end; r += rpi * U) {
+        float4 zv[U], gv[U], av[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ru = r + u * rpi;
+          ok[u] = ru < row_end;
+          const size_t off = ((size_t)n * g.HW + (ok[u] ? ru : r)) * g.C + c;
+          zv[u] = *reinterpret_cast<const float4*>(z + off);
+          if ((MODE == 1 || MODE == 2) && aio) av[u] = *reinterpret_cast<const float4*>(aio + off);
+          if (MODE == 1 || MODE == 2) gv[u] = *reinterpret_cast<const float4*>(gy + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
+          float4 a4;
+          if ((MODE == 1 || MODE == 2) && aio) a4 = av[u];
+          else a4 = act_fwd4(zv[u], act);
+          if ((MODE == 0 || MODE == 3) && aio) *reinterpret_cast<float4*>(aio + off) = a4;
+          if (MODE == 3) continue;
+          if (MODE == 0) {
+            s0[0] += a4.x; s0[1] += a4.y; s0[2] += a4.z; s0[3] += a4.w;
+            s1[0] += (double)a4.x * a4.x; s1[1] += (double)a4.y * a4.y;
+            s1[2] += (double)a4.z * a4.z; s1[3] += (double)a4.w * a4.w;
+          } else if (MODE == 1) {
+            s0[0] += gv[u].x; s0[1] += gv[u].y; s0[2] += gv[u].z; s0[3] += gv[u].w;
+            s1[0] += (double)gv[u].x * a4.x; s1[1] += (double)gv[u].y * a4.y;
+            s1[2] += (double)gv[u].z * a4.z; s1[3] += (double)gv[u].w * a4.w;
           } else {
             float4 d;
-            d.x = (a1.x * gv.x + a2.x * av.x + a3.x) * act_bwd(zv.x, act);
-            d.y = (a1.y * gv.y + a2.y * av.y + a3.y) * act_bwd(zv.y, act);
-            d.z = (a1.z * gv.z + a2.z * av.z + a3.z) * act_bwd(zv.z, act);
-            d.w = (a1.w * gv.w + a2.w * av.w + a3.w) * act_bwd(zv.w, act);
+            d.x = (a1.x * gv[u].x + a2.x * a4.x + a3.x) * act_bwd(zv[u].x, act);
+            d.y = (a1.y * gv[u].y + a2.y * a4.y + a3.y) * act_bwd(zv[u].y, act);
+            d.z = (a1.z * gv[u].z + a2.z * a4.z + a3.z) * act_bwd(zv[u].z, act);
+            d.w = (a1.w * gv[u].w + a2.w * a4.w + a3.w) * act_bwd(zv[u].w, act);
             *reinterpret_cast<float4*>(dz + off) = d;
             s0[0] += d.x; s0[1] += d.y; s0[2] += d.z; s0[3] += d.w;
           }
