@@ -146,17 +146,31 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict_
   }
 }
 
-// nc[s][n][c] = sum over chunks of part[n][chunk][s][c]
-__global__ void norm_reduce_chunks_kernel(const double* __restrict__ part, double* __restrict__ nc, NormGeom g,
-                                          int ns) {
+// nc[s][n][c] = sum over chunks of part[n][chunk][s][c]; 32 outputs x 8 chunk groups per workgroup, fixed order
+__global__ __launch_bounds__(256) void norm_reduce_chunks_kernel(const double* __restrict__ part, double* __restrict__ nc,
+                                                                 NormGeom g, int ns) {
+  __shared__ double red[8][32];
+  const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
   const int total = ns * g.N * g.C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int c = i % g.C;
-    const int n = (i / g.C) % g.N;
-    const int s = i / (g.C * g.N);
+  for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+    const int i = base + o;
     double acc = 0.0;
-    for (int k = 0; k < g.chunks; ++k) acc += part[(((size_t)n * g.chunks + k) * 3 + s) * g.C + c];
-    nc[((size_t)s * g.N + n) * g.C + c] = acc;
+    int c = 0, n = 0, sidx = 0;
+    if (i < total) {
+      c = i % g.C;
+      n = (i / g.C) % g.N;
+      sidx = i / (g.C * g.N);
+      for (int k = kg; k < g.chunks; k += 8) acc += part[(((size_t)n * g.chunks + k) * 3 + sidx) * g.C + c];
+    }
+    red[kg][o] = acc;
+    __syncthreads();
+    if (kg == 0 && i < total) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += red[j][o];
+      nc[((size_t)sidx * g.N + n) * g.C + c] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -324,7 +338,7 @@ extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, in
                      (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
                      part, act_out);
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
+  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
@@ -372,7 +386,7 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act, part,
                      const_cast<float*>(act_in));
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C)), dim3(256), 0, st,
+  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
@@ -383,7 +397,7 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
                      (const float*)k2, (const float*)k3, kss, g, act, part2, const_cast<float*>(act_in));
   MSEG_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C)), dim3(256), 0, st,
+    hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,
                        (const double*)part2, nc, g, 1);
     MSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_colsum_kernel, dim3(nblocks(C)), dim3(256), 0, st, (const double*)nc, g, dbias);

@@ -552,18 +552,44 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
 }
 
 // dst[(m*Nst + n)*T + t] = sum_s ws[((s*T + t)*Mch + m)*Nch + n]   (fixed order -> deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dst, int splits, int T,
-                                    int Mch, int Nch, int Nst) {
-  const size_t total = (size_t)T * Mch * Nch;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % Nch);
-    const size_t tm = i / Nch;
-    const int m = (int)(tm % Mch);
-    const int t = (int)(tm / Mch);
-    if (n >= Nst) continue;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
-    dst[((size_t)m * Nst + n) * T + t] = s;
+// A workgroup owns one m and NL = 256 / KG consecutive n, i.e. a CONTIGUOUS run of NL * T floats of dst: the T taps of
+// an (m, n) are summed together (T accumulators per thread, split range strided over KG thread groups), combined through
+// LDS in fixed order and written as full lines — instead of one scattered 4-byte store per thread.
+template <int KG>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dst,
+                                                           int splits, int T, int Mch, int Nch, int Nst) {
+  constexpr int NL = 256 / KG;
+  constexpr int TMAX = 9;
+  __shared__ float red[KG][TMAX][NL];
+  const int nl = threadIdx.x % NL, kg = threadIdx.x / NL;
+  const int nchunks = (Nch + NL - 1) / NL;
+  const int m = blockIdx.x / nchunks;
+  const int n0 = (blockIdx.x - m * nchunks) * NL;
+  const int n = n0 + nl;
+  float acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
+  if (n < Nch) {
+    const size_t tstride = (size_t)Mch * Nch;
+    const float* base = ws + (size_t)m * Nch + n;
+    for (int k = kg; k < splits; k += KG) {
+      const float* pk = base + (size_t)k * T * tstride;
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < T) acc[t] += pk[(size_t)t * tstride];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) red[kg][t][nl] = acc[t];
+  __syncthreads();
+  const int nrun = (Nst - n0 < NL ? Nst - n0 : NL) * T;          // floats of dst this workgroup owns
+  float* out = dst + ((size_t)m * Nst + n0) * T;
+  for (int e = threadIdx.x; e < nrun; e += 256) {
+    const int en = e / T, et = e - en * T;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < KG; ++j) v += red[j][et][en];
+    out[e] = v;
   }
 }
 
@@ -573,7 +599,8 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   const long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   const int per_split_wgs = tiles * p.KH;
-  long long s = p.splits > 0 ? p.splits : (1536 + per_split_wgs - 1) / per_split_wgs;
+  // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs
+  long long s = p.splits > 0 ? p.splits : (768 + per_split_wgs - 1) / per_split_wgs;
   if (s > steps_total) s = steps_total;
   if (s > 2048) s = 2048;
   if (s < 1) s = 1;
@@ -674,11 +701,16 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     MSEG_LAUNCH_CHECK();
   }
   if (p.phase == 1) return MSEG_OK;
-  const size_t total = (size_t)T * p.P.C * p.Nch;
-  unsigned blocks = (unsigned)((total + 255) / 256);
-  if (blocks > 8192u) blocks = 8192u;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T, p.P.C,
-                     p.Nch, p.Nch_store);
+  // many splits (few channel tiles: the wide shallow levels) -> 16 thread groups share the split range
+  if (splits >= 32) {
+    const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 15) / 16);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
+                       p.P.C, p.Nch, p.Nch_store);
+  } else {
+    const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 63) / 64);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
+                       p.P.C, p.Nch, p.Nch_store);
+  }
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
