@@ -105,6 +105,16 @@ typedef struct MsegWgrad {
 size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);
 int mseg_wgrad(const MsegWgrad* p, void* stream);
 
+/* The network's first convolution, Conv2d(ch_in <= 4, Cout, 3, padding=1) (unets.py:303-304,413-414), and its weight
+ * gradient for ch_in == 1: HBM-bound VALU kernels (9..36 multiply-adds per output), not worth a 32-channel matrix-core
+ * K-step.  x4: raw network input, NHWC with 4 channels (zero padded); w / dW: torch layout (Cout, Cin, 3, 3);
+ * z, dz: [N][H][W][Cout].  Cout % 4 == 0, Cout <= 256, 256 % (Cout / 4) == 0 — otherwise MSEG_EINVAL (use mseg_igemm). */
+int mseg_first_conv_fwd(const float* x4, const float* w, const float* bias, int N, int H, int W, int Cin, int Cout,
+                        float* z, void* stream);
+size_t mseg_first_wgrad_workspace_bytes(int N, int H, int W, int Cout);
+int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, int W, int Cout, float* dW, void* ws,
+                     void* stream);
+
 /* strided repack of a weight tensor into the zero-padded [T][Rpad][Cpad] GEMM operand:
  *   dst[(t*Rpad + r)*Cpad + c] = (r < R && c < C) ? src[t*st + r*sr + c*sc] : 0                             */
 int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C, int Cpad, int st, int sr, int sc,

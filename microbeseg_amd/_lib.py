@@ -53,6 +53,9 @@ _SZ = C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/mseg_hip.h
 SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
+    "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

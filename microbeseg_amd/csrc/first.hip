@@ -1,0 +1,175 @@
+// first.hip — the network's first convolution (Conv2d(ch_in, 64, 3, padding=1): src/utils/unets.py:303-304,413-414) and
+// its weight gradient.  With ch_in = 1 (4 with the zero padding of the input tensor) the layer has 9..36 multiply-adds per
+// output against a 256-byte output row: it is bound by the HBM write of z (forward) / the read of dz (weight gradient),
+// and running it through the 32-channel K-steps of the matrix-core kernels wastes 8/9 of their work.  Plain VALU kernels:
+//   forward: a thread owns 4 output channels of one pixel (16-byte store), weights of its 4 channels in registers;
+//   wgrad:   a thread owns 4 output channels and walks pixels, 9 x 4 running sums; fixed-order two-stage reduction.
+// The input x is the raw network input (no pending activation / normalisation), NHWC with C = 4 (zero padded).
+#include "common.h"
+
+#define FIRST_MAXC 256   // output channels handled (64 in every reference configuration)
+
+template <int CI>   // input channels actually multiplied: 1 (reference nets) or 4 (the padded tensor)
+__global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __restrict__ x4, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int N, int H, int W,
+                                                             int Cin, int Cout, float* __restrict__ z) {
+  // w: torch layout [Cout][Cin][3][3]; thread (pixel slot, channel quad)
+  const int CQ = Cout >> 2;                  // channel quads per pixel
+  const int ppb = 256 / CQ;                  // pixels per workgroup pass
+  const int cq = threadIdx.x % CQ, ps = threadIdx.x / CQ;
+  if (ps >= ppb) return;
+  const int co = cq * 4;
+  float wr[4][CI][9];                        // [co quad lane][ci][tap]; ci beyond Cin stay zero
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[j][ci][t] = (ci < Cin) ? w[((size_t)(co + j) * Cin + ci) * 9 + t] : 0.f;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b = *reinterpret_cast<const float4*>(bias + co);
+  const long long P = (long long)N * H * W;
+  for (long long p0 = (long long)blockIdx.x * ppb; p0 < P; p0 += (long long)gridDim.x * ppb) {
+    const long long pix = p0 + ps;
+    if (pix >= P) continue;
+    const int n = (int)(pix / ((long long)H * W));
+    const int rem = (int)(pix - (long long)n * H * W);
+    const int y = rem / W, x = rem - y * W;
+    float4 acc = b;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x4 + (((size_t)n * H + iy) * W + ix) * 4);
+        const int t = ky * 3 + kx;
+        acc.x += v.x * wr[0][0][t]; acc.y += v.x * wr[1][0][t]; acc.z += v.x * wr[2][0][t]; acc.w += v.x * wr[3][0][t];
+        if (CI > 1) {
+          acc.x += v.y * wr[0][1][t]; acc.y += v.y * wr[1][1][t]; acc.z += v.y * wr[2][1][t]; acc.w += v.y * wr[3][1][t];
+          acc.x += v.z * wr[0][2][t]; acc.y += v.z * wr[1][2][t]; acc.z += v.z * wr[2][2][t]; acc.w += v.z * wr[3][2][t];
+          acc.x += v.w * wr[0][3][t]; acc.y += v.w * wr[1][3][t]; acc.z += v.w * wr[2][3][t]; acc.w += v.w * wr[3][3][t];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(z + (size_t)pix * Cout + co) = acc;
+  }
+}
+
+// dW[co][0][t] = sum_p dz[p][co] * x[p + tap t][0]   (Cin = 1).  Stage 1: every workgroup reduces a contiguous pixel range
+// into part[block][9][Cout]; stage 2 sums the blocks in fixed order (deterministic, fp64).
+__global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restrict__ x4, const float* __restrict__ dz,
+                                                          int N, int H, int W, int Cout, int pix_per_block,
+                                                          float* __restrict__ part) {
+  __shared__ float red[9][256 * 4 / 4 * 4];   // [tap][pixel slot * Cout + channel]  (256 threads x 4 channels)
+  const int CQ = Cout >> 2;
+  const int ppb = 256 / CQ;
+  const int cq = threadIdx.x % CQ, ps = threadIdx.x / CQ;
+  const int co = cq * 4;
+  const long long P = (long long)N * H * W;
+  const long long pbeg = (long long)blockIdx.x * pix_per_block;
+  long long pend = pbeg + pix_per_block;
+  if (pend > P) pend = P;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ps < ppb) {
+    for (long long pix = pbeg + ps; pix < pend; pix += ppb) {
+      const int n = (int)(pix / ((long long)H * W));
+      const int rem = (int)(pix - (long long)n * H * W);
+      const int y = rem / W, x = rem - y * W;
+      const float4 g = *reinterpret_cast<const float4*>(dz + (size_t)pix * Cout + co);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = x + kx - 1;
+          const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+          const float v = ok ? x4[(((size_t)n * H + iy) * W + ix) * 4] : 0.f;
+          const int t = ky * 3 + kx;
+          acc[t].x += g.x * v; acc[t].y += g.y * v; acc[t].z += g.z * v; acc[t].w += g.w * v;
+        }
+      }
+    }
+  }
+  // combine the pixel slots of the workgroup (fixed order), one (tap, channel) per thread
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (ps < ppb) *reinterpret_cast<float4*>(&red[t][ps * Cout + co]) = acc[t];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * Cout; e += 256) {
+    const int t = e / Cout, c = e - t * Cout;
+    float s = 0.f;
+    for (int k = 0; k < ppb; ++k) s += red[t][k * Cout + c];
+    part[((size_t)blockIdx.x * 9 + t) * Cout + c] = s;
+  }
+}
+
+__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout, float* __restrict__ dW) {
+  // dW layout: torch (Cout, 1, 3, 3)
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 9 * Cout; e += gridDim.x * blockDim.x) {
+    const int t = e / Cout, c = e - t * Cout;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)part[((size_t)b * 9 + t) * Cout + c];
+    dW[(size_t)c * 9 + t] = (float)s;
+  }
+}
+
+static int first_blocks(long long P, int Cout, int* pix_per_block) {
+  const int ppb = 256 / (Cout >> 2);
+  long long blocks = 2048;
+  long long per = (P + blocks - 1) / blocks;
+  per = (per + ppb - 1) / ppb * ppb;
+  if (per < ppb) per = ppb;
+  blocks = (P + per - 1) / per;
+  *pix_per_block = (int)per;
+  return (int)blocks;
+}
+
+static bool first_shape_ok(int N, int H, int W, int Cin, int Cout) {
+  return N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 4 && Cout >= 4 && Cout <= FIRST_MAXC && (Cout & 3) == 0 &&
+         (256 % (Cout >> 2)) == 0;
+}
+
+extern "C" int mseg_first_conv_fwd(const float* x4, const float* w, const float* bias, int N, int H, int W, int Cin,
+                                   int Cout, float* z, void* stream) {
+  if (!x4 || !w || !z || !first_shape_ok(N, H, W, Cin, Cout)) return MSEG_EINVAL;
+  const long long P = (long long)N * H * W;
+  const int ppb = 256 / (Cout >> 2);
+  long long blocks = (P + ppb - 1) / ppb;
+  if (blocks > 8192) blocks = 8192;
+  if (Cin == 1)
+    hipLaunchKernelGGL((first_conv_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x4, w, bias,
+                       N, H, W, Cin, Cout, z);
+  else
+    hipLaunchKernelGGL((first_conv_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x4, w, bias,
+                       N, H, W, Cin, Cout, z);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" size_t mseg_first_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
+  if (!first_shape_ok(N, H, W, 1, Cout)) return 0;
+  int per;
+  const int blocks = first_blocks((long long)N * H * W, Cout, &per);
+  return (size_t)blocks * 9 * Cout * sizeof(float);
+}
+
+extern "C" int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, int W, int Cout, float* dW, void* ws,
+                                void* stream) {
+  if (!x4 || !dz || !dW || !ws || !first_shape_ok(N, H, W, 1, Cout)) return MSEG_EINVAL;
+  int per;
+  const int blocks = first_blocks((long long)N * H * W, Cout, &per);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x4, dz, N, H, W, Cout, per,
+                     (float*)ws);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, blocks,
+                     Cout, dW);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -364,6 +364,10 @@ class Tape:
         self.x4 = None
 
 
+def _first_layer_ok(cin, cout, stride):
+    return stride == 1 and 1 <= cin <= 4 and cout % 4 == 0 and cout <= 256 and 256 % (cout // 4) == 0
+
+
 def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
     conv = spec.conv
     n0 = in_nodes[0]
@@ -389,10 +393,15 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
             assert cin == cin_total, (cin, cin_total)
         else:
             assert _pad4(cin) == cin_total, (cin, cin_total)   # network input is zero-padded to 4 channels
-        wp = pack_weight(wt, 9, cout, cin, 1, cin * 9, 9)
         Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
         z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
-        igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
+        if first_layer_cin is not None and _first_layer_ok(cin, cout, stride):
+            # raw network input, 9..36 MACs per output: HBM-bound VALU kernel instead of a 32-channel MFMA K-step
+            check(_lib.load().mseg_first_conv_fwd(n0.z.data_ptr(), wt.contiguous().data_ptr(), bias.data_ptr(), N, Hi,
+                                                  Wi, cin, cout, z.data_ptr(), _stream()), "first_conv_fwd")
+        else:
+            wp = pack_weight(wt, 9, cout, cin, 1, cin * 9, 9)
+            igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
         act = spec.act
     node = Node(z, N, Ho, Wo, cout)
     node.act = act
@@ -557,8 +566,13 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
             cout, cin = wt.shape[0], wt.shape[1]
             stride = 2 if sp.kind == "pool" else 1
             is_first = i0 is tape.x4
-            wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride, 1,
-                  ws, nch_store=cin if is_first else None)
+            if is_first and cin == 1 and _first_layer_ok(cin, cout, stride):
+                w1 = ws.get("first_wgrad", lib.mseg_first_wgrad_workspace_bytes(N, node.H, node.W, cout))
+                check(lib.mseg_first_wgrad(i0.z.data_ptr(), dz.data_ptr(), N, node.H, node.W, cout, dW.data_ptr(),
+                                           w1.data_ptr(), _stream()), "first_wgrad")
+            else:
+                wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride,
+                      1, ws, nch_store=cin if is_first else None)
             if not is_first:
                 wp = pack_weight(wt, 9, cin, cout, 1, 9, cin * 9)
                 morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR

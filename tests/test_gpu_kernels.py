@@ -276,3 +276,33 @@ def test_head_forward_backward(eng, Cc, Co):
     assert rel_err(nchw(gx.cpu()), xin.grad) < TOL
     assert rel_err(dW.cpu(), w.grad.reshape(Co, Cc)) < TOL
     assert rel_err(db.cpu(), b.grad) < TOL
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 64, 24, 40), (1, 3, 16, 17, 9), (3, 1, 8, 32, 32)])
+def test_first_layer_kernels(eng, N, Cin, Cout, H, W):
+    """Conv2d(ch_in, Cout, 3, padding=1) on the raw (zero-padded to 4 channels) input + its weight gradient (ch_in 1)."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77 + Cout)
+    x = rnd(g, N, Cin, H, W)
+    w = (rnd(g, Cout, Cin, 3, 3) * 0.3).requires_grad_(True)
+    b = rnd(g, Cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    x4 = torch.zeros((N, H, W, 4))
+    x4[..., :Cin] = nhwc(x)
+    x4 = x4.cuda()
+    z = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    wd, bd = w.detach().cuda(), b.cuda()          # keep the device copies alive across the asynchronous launch
+    _lib.check(lib.mseg_first_conv_fwd(x4.data_ptr(), wd.data_ptr(), bd.data_ptr(), N, H, W, Cin, Cout, z.data_ptr(),
+                                       st), "first_conv_fwd")
+    assert rel_err(nchw(z.cpu()), ref.detach()) < TOL
+    if Cin == 1:
+        gy = rnd(g, N, Cout, H, W)
+        ref.backward(gy)
+        ws = torch.empty(lib.mseg_first_wgrad_workspace_bytes(N, H, W, Cout), dtype=torch.uint8, device="cuda")
+        dW = torch.full((Cout, 1, 3, 3), float("nan"), device="cuda")
+        gyd = nhwc(gy).cuda()
+        _lib.check(lib.mseg_first_wgrad(x4.data_ptr(), gyd.data_ptr(), N, H, W, Cout, dW.data_ptr(), ws.data_ptr(), st),
+                   "first_wgrad")
+        assert rel_err(dW.cpu(), w.grad) < TOL
