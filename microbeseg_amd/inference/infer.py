@@ -111,16 +111,72 @@ class InferWorker(QObject):
 
     def infer_stack(self, img):
         """[T, H, W] stack -> [T, H, W] uint16 masks; per frame min/max + top/left padding exactly like
-        infer_script_local.py:118-161 / infer.py:250-259."""
+        infer_script_local.py:118-161 / infer.py:250-259.
+
+        MI355X path for distance models: the frames are pipelined over two HIP streams — while the watershed of frame i
+        (a few long-running, latency-bound lanes) runs on the side stream, the matrix kernels of frame i+1 run on the
+        main stream, and the uint16 mask travels back through a pinned buffer.  Results are identical to calling
+        ``inference`` frame by frame."""
         results = np.zeros(shape=(img.shape[0], img.shape[1], img.shape[2]), dtype=np.uint16)
-        for frame in range(len(img)):
-            if self.stop_inference:
-                break
-            img_frame = np.copy(img[frame])
-            frame_min, frame_max = np.min(img_frame), np.max(img_frame)
-            img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
-            results[frame] = self.inference(img_frame, frame_min, frame_max, pads)
-            self.progress.emit(int(100 * (frame + 1) / len(img)))
+        pipelined = (self.model_settings is not None and self.model_settings['label_type'] == 'distance'
+                     and self.device.type == 'cuda')
+        if not pipelined:
+            for frame in range(len(img)):
+                if self.stop_inference:
+                    break
+                img_frame = np.copy(img[frame])
+                frame_min, frame_max = np.min(img_frame), np.max(img_frame)
+                img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
+                results[frame] = self.inference(img_frame, frame_min, frame_max, pads)
+                self.progress.emit(int(100 * (frame + 1) / len(img)))
+            return results
+
+        self.net.eval()
+        torch.set_grad_enabled(False)
+        side = torch.cuda.Stream(device=self.device)
+        pending = []      # (frame index, pinned host mask, event on the side stream)
+
+        def finish(entry):
+            f, host, ev = entry
+            if ev is not None:
+                ev.synchronize()
+                results[f] = host.numpy().view(np.uint16)
+            self.progress.emit(int(100 * (f + 1) / len(img)))
+
+        with torch.cuda.device(self.device):
+            for frame in range(len(img)):
+                if self.stop_inference:
+                    break
+                img_frame = np.copy(img[frame])
+                frame_min, frame_max = np.min(img_frame), np.max(img_frame)
+                img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
+                img_batch = 2 * (img_frame.astype(np.float32) - frame_min) / (frame_max - frame_min) - 1
+                img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
+                try:
+                    img_batch = img_batch.to(self.device)
+                    border, cell = self.net(img_batch)
+                    cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
+                    border = border[0, 0, pads[0]:, pads[1]:].contiguous()
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1],
+                                                                         th_cell=self.ths[0], col_major_ids=True)
+                        border.record_stream(side)
+                        cell.record_stream(side)
+                        host = torch.empty(labels.shape, dtype=torch.int16, pin_memory=True)
+                        host.copy_(labels, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    pending.append((frame, host, done))
+                except RuntimeError:   # zero mask instead of a crash, like inference() (infer.py:354-356)
+                    self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
+                    pending.append((frame, None, None))
+                while len(pending) > 2:          # two frames in flight
+                    finish(pending.pop(0))
+            while pending:
+                finish(pending.pop(0))
         return results
 
     @pyqtSlot()

@@ -136,3 +136,13 @@ def test_train_worker_on_gpu_configs0(tmp_path, label_type, optimizer):
     frame = (np.random.default_rng(0).random((100, 130)) * 4000).astype(np.uint16)
     masks = iw.infer_stack(frame[None])
     assert masks.shape == (1, 100, 130) and masks.dtype == np.uint16
+    # a stack is pipelined over two streams (distance models): every mask equals the frame-by-frame result
+    rng = np.random.default_rng(1)
+    stack = (rng.random((5, 100, 130)) * 4000).astype(np.uint16)
+    masks = iw.infer_stack(stack)
+    from microbeseg_amd.utils.utils import zero_pad_model_input
+    for t in range(len(stack)):
+        f = np.copy(stack[t])
+        fmin, fmax = np.min(f), np.max(f)
+        fp, pads = zero_pad_model_input(f, pad_val=fmin)
+        assert np.array_equal(masks[t], iw.inference(fp, fmin, fmax, pads))
