@@ -109,13 +109,24 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restric
   }
 }
 
-__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout, float* __restrict__ dW) {
-  // dW layout: torch (Cout, 1, 3, 3)
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 9 * Cout; e += gridDim.x * blockDim.x) {
-    const int t = e / Cout, c = e - t * Cout;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)part[((size_t)b * 9 + t) * Cout + c];
-    dW[(size_t)c * 9 + t] = (float)s;
+// fixed-order sum over the workgroup partials: 32 outputs x 8 partial groups per workgroup, combined through LDS
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout,
+                                                                 float* __restrict__ dW) {
+  __shared__ double red[8][32];
+  const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + o;
+  const bool live = e < 9 * Cout;
+  const int t = live ? e / Cout : 0, c = live ? e - t * Cout : 0;
+  double s = 0.0;
+  if (live)
+    for (int b = kg; b < nblocks; b += 8) s += (double)part[((size_t)b * 9 + t) * Cout + c];
+  red[kg][o] = s;
+  __syncthreads();
+  if (kg == 0 && live) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += red[j][o];
+    dW[(size_t)c * 9 + t] = (float)v;          // torch layout (Cout, 1, 3, 3)
   }
 }
 
@@ -168,7 +179,7 @@ extern "C" int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, 
   hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x4, dz, N, H, W, Cout, per,
                      (float*)ws);
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 255) / 256), dim3(256), 0, st, (const float*)ws, blocks,
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks,
                      Cout, dW);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;

@@ -171,19 +171,28 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom
   }
 }
 
-__global__ void head_bwd_reduce_kernel(const double* __restrict__ part, HeadGeom g, float* __restrict__ dW,
-                                       float* __restrict__ db) {
+// sums the per-workgroup partials in fixed order: 32 outputs x 8 partial groups per workgroup, combined through LDS
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const double* __restrict__ part, HeadGeom g,
+                                                              float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ double red[8][32];
   const int per = HEAD_MAXCO * (g.C + 1);
   const int blocks = g.N * g.chunks;
   const int total = g.Co * g.C + g.Co;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int slot;
-    if (i < g.Co * g.C) slot = i;  // [co][c]
-    else slot = HEAD_MAXCO * g.C + (i - g.Co * g.C);
-    double s = 0.0;
-    for (int k = 0; k < blocks; ++k) s += part[(size_t)k * per + slot];
-    if (i < g.Co * g.C) dW[i] = (float)s;
-    else if (db) db[i - g.Co * g.C] = (float)s;
+  const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  double s = 0.0;
+  if (i < total) {
+    const int slot = (i < g.Co * g.C) ? i : HEAD_MAXCO * g.C + (i - g.Co * g.C);   // [co][c] then the bias sums
+    for (int k = kg; k < blocks; k += 8) s += part[(size_t)k * per + slot];
+  }
+  red[kg][o] = s;
+  __syncthreads();
+  if (kg == 0 && i < total) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][o];
+    if (i < g.Co * g.C) dW[i] = (float)t;
+    else if (db) db[i - g.Co * g.C] = (float)t;
   }
 }
 
@@ -195,7 +204,7 @@ extern "C" int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, *src, g, w, gout_nchw, gy, (double*)ws);
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((Co * (src->C + 1) + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((Co * (src->C + 1) + 31) / 32), dim3(256), 0, st,
                      (const double*)ws, g, dW, db);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
