@@ -206,6 +206,26 @@ int mseg_distance_postprocess(const float* border, const float* cell, int H, int
 int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, uint16_t* labels, int32_t* n_instances_dev,
                               int32_t* status_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* Threshold sweep of the evaluation (EvalWorker.inference, src/evaluation/eval.py:127-131,397-409: one
+ * distance_postprocessing per (th_cell, th_seed) pair on the same prediction).  The smoothed cell map is computed once;
+ * th_cell / th_seed are HOST arrays of nth floats; labels [nth][H][W], n_instances_dev / status_dev [nth] (nullable). */
+int mseg_distance_postprocess_sweep(const float* border, const float* cell, int H, int W, const float* th_cell,
+                                    const float* th_seed, int nth, int col_major_ids, uint16_t* labels,
+                                    int32_t* n_instances_dev, int32_t* status_dev, void* ws, size_t ws_bytes,
+                                    void* stream);
+
+/* ---- evaluation helpers (EvalWorker.calc_scores, src/evaluation/eval.py:248-256) -----------------
+ * mseg_eval_relabel: border_correction(mask, border_width) (src/utils/utils.py:25-47: instances not visible inside the
+ *   frame minus its border are deleted) followed by skimage.measure.label (8-neighbours of EQUAL value connect; new ids
+ *   1..K in raster order of each component's first pixel) -> lab_out int32 [H][W], *n_out_dev = K.
+ * mseg_eval_pair_counts: the integer statistics of get_fast_aji_plus (src/evaluation/stats_utils.py:98-179) for two
+ *   contiguous label images: area_t[nt+1], area_p[np+1], inter[nt+1][np+1] (device arrays, zeroed by the call).     */
+size_t mseg_eval_workspace_bytes(int H, int W);
+int mseg_eval_relabel(const uint16_t* mask, int H, int W, int border_width, int32_t* lab_out, int32_t* n_out_dev,
+                      void* ws, size_t ws_bytes, void* stream);
+int mseg_eval_pair_counts(const int32_t* true_lab, const int32_t* pred_lab, int H, int W, int nt, int np,
+                          int32_t* area_t, int32_t* area_p, int32_t* inter, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------------------------- */
 int mseg_version(void);
 const char* mseg_strerror(int code);

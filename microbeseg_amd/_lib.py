@@ -80,6 +80,11 @@ SIGNATURES = {
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "mseg_distance_postprocess_sweep": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P, _P,
+                                             _P, _P, _SZ, _P]),
+    "mseg_eval_workspace_bytes": (_SZ, [_I, _I]),
+    "mseg_eval_relabel": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "mseg_eval_pair_counts": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mseg_version": (_I, []),
     "mseg_strerror": (C.c_char_p, [_I]),
     "mseg_last_hip_error": (_I, []),

@@ -638,6 +638,27 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
   return MSEG_OK;
 }
 
+static int pp_distance_smooth(const PPWs& w, const float* cell, int H, int W, hipStream_t st) {
+  const size_t n = (size_t)H * W;
+  const unsigned nb = pp_blocks(n);
+  double gw[3];
+  pp_gauss_weights(gw);
+  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, cell, w.tmp, H, W, 0, gw[0], gw[1], gw[2]);
+  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.tmp, w.cs, H, W, 1, gw[0], gw[1], gw[2]);
+  hipLaunchKernelGGL(pp_negate_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.cs, w.tmp, n);  // image = -cell
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+static int pp_distance_tail(const PPWs& w, const float* border, int H, int W, float th_cell, float th_seed,
+                            int col_major_ids, uint16_t* labels, int32_t* n_inst, int32_t* status, hipStream_t st) {
+  const size_t n = (size_t)H * W;
+  hipLaunchKernelGGL(pp_distance_thresh_kernel, dim3(pp_blocks(n)), dim3(PP_BLOCK), 0, st, border, (const float*)w.cs, n,
+                     th_cell, th_seed, w.mask, w.seedb);
+  MSEG_LAUNCH_CHECK();
+  return pp_seeds_to_labels(w, w.tmp, H, W, 1, col_major_ids, 0, labels, n_inst, status, st);
+}
+
 extern "C" int mseg_distance_postprocess(const float* border, const float* cell, int H, int W, float th_cell,
                                          float th_seed, int col_major_ids, uint16_t* labels, int32_t* n_instances_dev,
                                          int32_t* status_dev, void* ws, size_t ws_bytes, void* stream) {
@@ -648,17 +669,33 @@ extern "C" int mseg_distance_postprocess(const float* border, const float* cell,
   hipStream_t st = (hipStream_t)stream;
   PPWs w;
   pp_carve(&w, ws, H, W);
+  if (pp_distance_smooth(w, cell, H, W, st)) return MSEG_ELAUNCH;
+  return pp_distance_tail(w, border, H, W, th_cell, th_seed, col_major_ids, labels, n_instances_dev, status_dev, st);
+}
+
+// Threshold sweep of the evaluation (EvalWorker.inference: src/evaluation/eval.py:127-131,397-409 runs
+// distance_postprocessing once per (th_cell, th_seed) pair on the same prediction): the smoothed cell map does not depend
+// on the thresholds, so it is computed once; thresholds / seeds / watershed run per pair.  labels: [nth][H][W].
+extern "C" int mseg_distance_postprocess_sweep(const float* border, const float* cell, int H, int W,
+                                               const float* th_cell, const float* th_seed, int nth, int col_major_ids,
+                                               uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev, void* ws,
+                                               size_t ws_bytes, void* stream) {
+  if (!border || !cell || !labels || !ws || !th_cell || !th_seed || nth <= 0 || H <= 0 || W <= 0) return MSEG_EINVAL;
+  const size_t need = mseg_postproc_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PPWs w;
+  pp_carve(&w, ws, H, W);
+  if (pp_distance_smooth(w, cell, H, W, st)) return MSEG_ELAUNCH;
   const size_t n = (size_t)H * W;
-  const unsigned nb = pp_blocks(n);
-  double gw[3];
-  pp_gauss_weights(gw);
-  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, cell, w.tmp, H, W, 0, gw[0], gw[1], gw[2]);
-  hipLaunchKernelGGL(pp_gauss_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.tmp, w.cs, H, W, 1, gw[0], gw[1], gw[2]);
-  hipLaunchKernelGGL(pp_distance_thresh_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, border, (const float*)w.cs, n,
-                     th_cell, th_seed, w.mask, w.seedb);
-  hipLaunchKernelGGL(pp_negate_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const float*)w.cs, w.tmp, n);  // image = -cell
-  MSEG_LAUNCH_CHECK();
-  return pp_seeds_to_labels(w, w.tmp, H, W, 1, col_major_ids, 0, labels, n_instances_dev, status_dev, st);
+  for (int i = 0; i < nth; ++i) {
+    const int rc = pp_distance_tail(w, border, H, W, th_cell[i], th_seed[i], col_major_ids, labels + (size_t)i * n,
+                                    n_instances_dev ? n_instances_dev + i : nullptr, status_dev ? status_dev + i : nullptr,
+                                    st);
+    if (rc) return rc;
+  }
+  return MSEG_OK;
 }
 
 extern "C" int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, uint16_t* labels,
@@ -677,4 +714,130 @@ extern "C" int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, u
   MSEG_LAUNCH_CHECK();
   // constant image: every key ties -> the order is the global heap's; go straight to the exact serial flood
   return pp_seeds_to_labels(w, w.tmp, H, W, 0, 0, 1, labels, n_instances_dev, status_dev, st);
+}
+
+// =====================================================================================================================
+// Evaluation helpers — EvalWorker.calc_scores (src/evaluation/eval.py:248-256) per test image:
+//   border_correction (src/utils/utils.py:25-47) -> skimage.measure.label -> get_fast_aji_plus (stats_utils.py:98-179).
+// On the device: the relabelling (instances not visible inside the field of interest dropped; 8-connected components of
+// EQUAL value; ids in raster order of the first pixel) and the integer statistics AJI+ is made of (areas, pairwise
+// intersections).  The Hungarian pairing on the small IoU matrix stays on the host (the reference calls scipy for it).
+struct EvWs {
+  int32_t* val; int32_t* L; int32_t* flag; int32_t* scan; int32_t* bsum; uint8_t* seen;
+};
+
+static size_t ev_carve(EvWs* w, void* base, int H, int W) {
+  const size_t n = (size_t)H * W;
+  const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+  size_t off = 0;
+  char* b = (char*)base;
+#define EV_TAKE(field, type, count)                         \
+  do {                                                      \
+    off = align_up(off, 256);                               \
+    if (w) w->field = (type*)(b + off);                     \
+    off += sizeof(type) * (size_t)(count);                  \
+  } while (0)
+  EV_TAKE(val, int32_t, n); EV_TAKE(L, int32_t, n); EV_TAKE(flag, int32_t, n); EV_TAKE(scan, int32_t, n);
+  EV_TAKE(bsum, int32_t, 2 * nb); EV_TAKE(seen, uint8_t, 65536);
+#undef EV_TAKE
+  return align_up(off, 256);
+}
+
+extern "C" size_t mseg_eval_workspace_bytes(int H, int W) {
+  if (H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL) return 0;
+  return ev_carve(nullptr, nullptr, H, W);
+}
+
+__global__ void ev_seen_kernel(const uint16_t* __restrict__ mask, int H, int W, int bw, uint8_t* __restrict__ seen) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  if (y >= bw && y < H - bw && x >= bw && x < W - bw) seen[mask[i]] = 1;   // ids visible in the field of interest
+}
+
+__global__ void ev_filter_kernel(const uint16_t* __restrict__ mask, size_t n, const uint8_t* __restrict__ seen,
+                                 int32_t* __restrict__ val, int32_t* __restrict__ L) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = (mask[i] != 0 && seen[mask[i]]) ? (int)mask[i] : 0;
+  val[i] = v;
+  L[i] = v ? (int32_t)i : -1;
+}
+
+__global__ void ev_merge_kernel(const int32_t* __restrict__ val, int32_t* __restrict__ L, int H, int W) {
+  const size_t n = (size_t)H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = val[i];
+  if (!v) return;
+  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  if (x > 0 && val[i - 1] == v) uf_union(L, (int)i, (int)i - 1);
+  if (y > 0) {
+    if (val[i - W] == v) uf_union(L, (int)i, (int)i - W);
+    if (x > 0 && val[i - W - 1] == v) uf_union(L, (int)i, (int)i - W - 1);
+    if (x + 1 < W && val[i - W + 1] == v) uf_union(L, (int)i, (int)i - W + 1);
+  }
+}
+
+__global__ void ev_rootflag_kernel(const int32_t* __restrict__ L, size_t n, int32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (L[i] == (int32_t)i) ? 1 : 0;   // the root is the component's smallest raster index = first pixel
+}
+
+__global__ void ev_assign_kernel(const int32_t* __restrict__ L, const int32_t* __restrict__ scan, size_t n,
+                                 int32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = L[i] >= 0 ? scan[L[i]] + 1 : 0;
+}
+
+extern "C" int mseg_eval_relabel(const uint16_t* mask, int H, int W, int border_width, int32_t* lab_out,
+                                 int32_t* n_out_dev, void* ws, size_t ws_bytes, void* stream) {
+  if (!mask || !lab_out || !n_out_dev || !ws || H <= 0 || W <= 0 || border_width < 0) return MSEG_EINVAL;
+  const size_t need = mseg_eval_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  EvWs w;
+  ev_carve(&w, ws, H, W);
+  const size_t n = (size_t)H * W;
+  const unsigned nb = pp_blocks(n);
+  (void)hipMemsetAsync(w.seen, 0, 65536, st);
+  hipLaunchKernelGGL(ev_seen_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, mask, H, W, border_width, w.seen);
+  hipLaunchKernelGGL(ev_filter_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, mask, n, (const uint8_t*)w.seen, w.val, w.L);
+  hipLaunchKernelGGL(ev_merge_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.val, w.L, H, W);
+  hipLaunchKernelGGL(pp_ccl_flatten_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.L, n);
+  hipLaunchKernelGGL(ev_rootflag_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.L, n, w.flag);
+  MSEG_LAUNCH_CHECK();
+  if (pp_exclusive_scan(w.flag, w.scan, w.bsum, n, n_out_dev, st)) return MSEG_ELAUNCH;
+  hipLaunchKernelGGL(ev_assign_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.L, (const int32_t*)w.scan, n,
+                     lab_out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+__global__ void ev_pair_kernel(const int32_t* __restrict__ t, const int32_t* __restrict__ p, size_t n, int nt, int np,
+                               int32_t* __restrict__ area_t, int32_t* __restrict__ area_p,
+                               int32_t* __restrict__ inter) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = t[i], b = p[i];
+  if (a < 0 || a > nt || b < 0 || b > np) return;     // ids outside the declared range are ignored
+  if (a) atomicAdd(&area_t[a], 1);
+  if (b) atomicAdd(&area_p[b], 1);
+  if (a && b) atomicAdd(&inter[(size_t)a * (np + 1) + b], 1);
+}
+
+extern "C" int mseg_eval_pair_counts(const int32_t* true_lab, const int32_t* pred_lab, int H, int W, int nt, int np,
+                                     int32_t* area_t, int32_t* area_p, int32_t* inter, void* stream) {
+  if (!true_lab || !pred_lab || !area_t || !area_p || !inter || H <= 0 || W <= 0 || nt < 0 || np < 0) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)H * W;
+  (void)hipMemsetAsync(area_t, 0, sizeof(int32_t) * (size_t)(nt + 1), st);
+  (void)hipMemsetAsync(area_p, 0, sizeof(int32_t) * (size_t)(np + 1), st);
+  (void)hipMemsetAsync(inter, 0, sizeof(int32_t) * (size_t)(nt + 1) * (size_t)(np + 1), st);
+  hipLaunchKernelGGL(ev_pair_kernel, dim3(pp_blocks(n)), dim3(PP_BLOCK), 0, st, true_lab, pred_lab, n, nt, np, area_t,
+                     area_p, inter);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
 }

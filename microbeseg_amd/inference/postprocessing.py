@@ -68,6 +68,30 @@ def distance_postprocessing_device(border, cell, th_seed, th_cell, col_major_ids
     return labels, info[0], info[1]
 
 
+def distance_postprocessing_sweep_device(border, cell, ths, col_major_ids=True):
+    """Threshold sweep of the evaluation (reference: src/evaluation/eval.py:127-131,397-409 calls distance_postprocessing
+    once per (th_cell, th_seed) pair on the same prediction).  border / cell: float32 CUDA tensors (H, W); ths: sequence
+    of (th_cell, th_seed).  Returns (labels int16-view-of-uint16 CUDA tensor (n, H, W), n_instances int32 (n,),
+    status int32 (n,)); labels[i] equals distance_postprocessing_device(border, cell, th_seed_i, th_cell_i)."""
+    import ctypes as C
+    lib = _lib.load()
+    H, W = cell.shape
+    dev = cell.device
+    nth = len(ths)
+    if nth == 0:
+        raise RuntimeError("empty threshold list")
+    ws, need = _workspace(dev, H, W)
+    labels = torch.empty((nth, H, W), dtype=torch.int16, device=dev)
+    info = torch.zeros((2, nth), dtype=torch.int32, device=dev)
+    tc = (C.c_float * nth)(*[float(t[0]) for t in ths])
+    ts = (C.c_float * nth)(*[float(t[1]) for t in ths])
+    _lib.check(lib.mseg_distance_postprocess_sweep(border.data_ptr(), cell.data_ptr(), H, W, tc, ts, nth,
+                                                   1 if col_major_ids else 0, labels.data_ptr(), info[0].data_ptr(),
+                                                   info[1].data_ptr(), ws.data_ptr(), need, _stream()),
+               "distance_postprocess_sweep")
+    return labels, info[0], info[1]
+
+
 def distance_postprocessing(border_prediction, cell_prediction, th_seed, th_cell):
     """ Post-processing for distance label (cell + neighbor) prediction (reference postprocessing.py:7).
 

@@ -11,6 +11,25 @@ TESTED_IMG_SHAPES = (64, 128, 256, 320, 512, 768, 1024, 1280, 1408, 1600, 1920, 
                      6080, 8192)
 
 
+def get_nucleus_ids(img):
+    """ Ids (> 0) present in an intensity-coded label image (reference utils.py:11-22). """
+    values = np.unique(img)
+    return values[values > 0]
+
+
+def border_correction(mask, border_width=10):
+    """ Delete (in place, like the reference: utils.py:25-47) the instances that are not visible inside the field of
+    interest = the mask minus a border of ``border_width`` pixels.  Host helper with the reference's signature; the
+    evaluation itself uses the fused device kernel (evaluation/stats_utils.py: relabel_device). """
+    ids_prediction = get_nucleus_ids(mask)
+    foi = mask[border_width:mask.shape[0] - border_width, border_width:mask.shape[1] - border_width]
+    ids_foi = get_nucleus_ids(foi)
+    for id_prediction in ids_prediction:
+        if id_prediction not in ids_foi:
+            mask[mask == id_prediction] = 0
+    return mask
+
+
 def min_max_normalization(img, min_value=None, max_value=None):
     """ Clip to [min_value, max_value] and map to [-1, 1] (float32). """
     if max_value is None:
