@@ -25,3 +25,31 @@ t0 = time.time(); want = R.distance_postprocessing(border[..., None], cell[..., 
 print(f"CPU oracle (1 thread) {dt*1e3:.0f} ms/frame  {H*W/dt/1e6:.2f} Mpx/s")
 got = labels.cpu().numpy().view(np.uint16)
 print("bit-exact:", bool(np.array_equal(got, want)), "mismatch px", int((got != want).sum()))
+
+# ---- evaluation: 4 x 2 threshold sweep (one call, shared smoothing) vs 8 separate calls; AJI+ scoring of one pair ----
+from microbeseg_amd.evaluation import stats_utils as su
+from oracle import eval_ref
+ths = [(tc, ts) for tc in (0.05, 0.075, 0.10, 0.125) for ts in (0.35, 0.45)]
+pp.distance_postprocessing_sweep_device(b, c, ths); torch.cuda.synchronize()
+e0.record()
+for _ in range(reps):
+    lab8, _, _ = pp.distance_postprocessing_sweep_device(b, c, ths)
+e1.record(); torch.cuda.synchronize()
+ms_sweep = e0.elapsed_time(e1) / reps
+e0.record()
+for _ in range(reps):
+    for tc, ts in ths:
+        pp.distance_postprocessing_device(b, c, th_seed=ts, th_cell=tc)
+e1.record(); torch.cuda.synchronize()
+ms_sep = e0.elapsed_time(e1) / reps
+print(f"sweep of 8 threshold pairs: {ms_sweep:.1f} ms in one call, {ms_sep:.1f} ms as 8 calls  ({8*H*W/ms_sweep/1e3:.0f} Mpx/s)")
+m0 = lab8[2].contiguous(); m1 = lab8[5].contiguous()
+su.aji_plus_masks(m0, m1); torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(reps):
+    aji = su.aji_plus_masks(m0, m1)
+dt = (time.time() - t0) / reps
+a, bb = m0.cpu().numpy().view(np.uint16), m1.cpu().numpy().view(np.uint16)
+t0 = time.time(); want_aji = eval_ref.score_pair(a, bb); dt_cpu = time.time() - t0
+print(f"AJI+ of two {H}x{W} masks ({int(a.max())} / {int(bb.max())} instances): HIP+host pairing {dt*1e3:.1f} ms, numpy/scipy oracle {dt_cpu*1e3:.0f} ms, "
+      f"equal: {abs(aji - want_aji) < 1e-12}")
