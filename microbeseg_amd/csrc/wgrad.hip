@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const MsegWgrad p, int split
 //   * buffer-descriptor loads with 32-bit offsets, out-of-range offset for padding taps / the pixel tail (returns 0);
 //   * P (the output gradient dz of a conv, or the convT input) and Q are transformed only if they carry a transform
 //     (PTR / QTR: 0 plain, 1 none|ReLU + affine, 2 any activation + affine).
-// Preconditions (host): operands < 2 GiB, per-channel (not per-sample) tables, concat boundary multiple of 64.
+// Preconditions (host): operands < 2 GiB, concat boundary multiple of 64, and for per-sample (Group/InstanceNorm) tables
+// an image size that is a multiple of the 32-pixel K-step.
 template <int KWT, int PTR, int QTR>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int splits, int steps_per_split) {
   constexpr int SLAB = WG_PIX * WG_LDS;
@@ -292,8 +293,29 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int 
   float4 rp[2], rq[KWT][2];
   float pm[2], qm[KWT][2];
 
+  // per-sample (Group/InstanceNorm) tables: a 32-pixel step lies in ONE image (Hp*Wp % 32 == 0, host-checked), so the
+  // tables of the step are wave-uniform in n and are re-read only when the image changes
+  const bool p_ps = PTR && p.P.scale && p.P.ss != 0;
+  const bool q_ps = QTR && qs.scale && qs.ss != 0;
+  const int HWp = p.Hp * p.Wp;
+  int sn = pix_begin / HWp, srem = pix_begin - sn * HWp;    // image of the next step to load (scalar)
+  int tab_n = -1;
+
   auto issue = [&](int step) {          // loads of `step`; then advances the pixel state to step + 1
     const unsigned psoff = (unsigned)(pix_begin + step * WG_PIX) * mC4;        // scalar
+    if ((p_ps || q_ps) && step < nsteps && sn != tab_n) {
+      tab_n = sn;
+      if (p_ps) {
+        psc = *reinterpret_cast<const float4*>(p.P.scale + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+        psh = *reinterpret_cast<const float4*>(p.P.shift + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+      }
+      if (q_ps) {
+        qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+        qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      }
+    }
+    srem += WG_PIX;
+    if (srem >= HWp) { srem -= HWp; sn += 1; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool inr = pp[i] < pix_end;
@@ -459,8 +481,25 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   float4 rp[2], rq[3];
   float pm, qm[3];
 
+  // per-sample (Group/InstanceNorm) tables: a 32-pixel step lies in ONE image (H*W % 32 == 0, host-checked), so the
+  // tables of the step are wave-uniform in n and are re-read only when the image changes
+  const bool p_ps = PTR && p.P.scale && p.P.ss != 0;
+  const bool q_ps = QTR && qs.scale && qs.ss != 0;
+  int tab_n = -1;
+
   auto issue = [&](int step) {
     const bool live = step < nsteps;                                             // scalar
+    if ((p_ps || q_ps) && live && sn != tab_n) {
+      tab_n = sn;
+      if (p_ps) {
+        psc = *reinterpret_cast<const float4*>(p.P.scale + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+        psh = *reinterpret_cast<const float4*>(p.P.shift + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+      }
+      if (q_ps) {
+        qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+        qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      }
+    }
     const unsigned psoff = (unsigned)(pix_begin + step * WG_PIX) * mC4;          // scalar, P rows are consecutive pixels
     const bool pok = live & mvalid;
 #pragma unroll
@@ -649,7 +688,9 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)p.KH), block(256);
     // fast path preconditions (see wgrad_fast_kernel)
     const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
-    bool fast = !per_sample && Ptot64 * p.P.C * 4 < 0x80000000LL && (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
+    // per-sample tables (Group/InstanceNorm) ride the fast paths when a 32-pixel K-step cannot straddle two images
+    bool fast = (!per_sample || ((long long)p.Hp * p.Wp) % WG_PIX == 0) && Ptot64 * p.P.C * 4 < 0x80000000LL &&
+                (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
     for (int i = 0; i < p.nq; ++i)
       if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) fast = false;
     if (p.nq > 1 && (p.Q[0].C % 64)) fast = false;

@@ -143,7 +143,8 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok
 def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
-    fast = (not per_sample) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
+    fast = ((not per_sample) or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and \
+        all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
     fast = fast and (len(Qs) == 1 or Qs[0].C % 64 == 0)
     if fast and KW == 3 and stride == 1 and Wp % 32 == 0 and Hq == Hp and Wq == Wp:
         return "wgrad_halo_kernel<%d, %d>" % (_tr_of(P), max(_tr_of(s) for s in Qs))
