@@ -962,7 +962,10 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const int TH = 128 >> tw_log2;
     const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
     const long long htiles = mt * ((p.Ngemm + BNv - 1) / BNv);
-    if (htiles <= 0x7fffffffLL) {
+    // rows of the 128-pixel tile that fall below the image are wasted matrix work (e.g. 20 x 20 images: 4 x 32 tiles
+    // cover 32 rows for 20); below 80 % the linear-M gather kernel, which wastes nothing, is the faster choice
+    const bool efficient = (long long)p.Hi * 5 >= (long long)((p.Hi + TH - 1) / TH) * TH * 4;
+    if (htiles <= 0x7fffffffLL && efficient) {
       const int tr = plain ? 0 : (generic ? 2 : 1);
       const dim3 hgrid((unsigned)htiles);
 #define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, p, tw_log2)

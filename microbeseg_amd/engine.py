@@ -153,6 +153,16 @@ def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
 
 
+def _halo_tile_efficient(Hi, Wi):
+    """mirror of the launcher's rule: 128-pixel halo tiles (TW = largest power of two <= 64 dividing W) are used only if
+    at least 80 % of their rows fall inside the image"""
+    tw = 64
+    while Wi % tw:
+        tw //= 2
+    th = 128 // tw
+    return Hi * 5 >= ((Hi + th - 1) // th) * th * 4
+
+
 def set_kernel_timer(t):
     global _timer
     _timer = t
@@ -216,7 +226,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
                                                halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
                                                         and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
-                                                        and Wi % 4 == 0),
+                                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi)),
                                                parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)),
                             flops)
     e0.record()
