@@ -408,15 +408,21 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const MsegWgrad p, int 
 }
 
 // =====================================================================================================================
-// Row-halo variant for the 3x3 stride-1 convolutions whose row length is a multiple of 32 (all but the deepest level of
-// the default net): a 32-pixel K-step then lies inside ONE image row, so the three x-shifted Q slabs of a kernel row are
-// one 34-pixel slab read at row offsets 0 / 1 / 2.  Q is loaded and normalised once instead of three times, and the
-// pixel position of a step is wave-uniform (scalar registers): per staged row the K-loop spends one add and one range
-// check on addressing.  LDS per stage: (32 + 34) x 68 floats.
-template <int PTR, int QTR>
+// Halo variant for the 3x3 stride-1 convolutions.  A K-step is a TH x TW block of 32 pixels of one image (TW = largest
+// power of two <= 32 dividing the row length, TH = 32 / TW), so the three x-shifted Q slabs of a kernel row are ONE
+// (TH) x (TW + 2) halo slab read at column offsets 0 / 1 / 2: Q is loaded and normalised once instead of three times.
+// The block position is wave-uniform (scalar registers) and every staged row has a constant offset relative to it, so
+// per staged row the K-loop spends one add and a range check on addressing; the LDS rows of the MFMA B fragments
+// (pixel k -> slab row (k / TW) * (TW + 2) + k % TW) are per-lane constants.  Blocks that hang over the bottom of the
+// image (H % TH != 0) contribute zeros through the P operand.  LDS per stage: (32 + up to 48) x 68 floats.
+// TWL = log2(TW) is a template parameter so that the LDS offsets of the B fragments are immediates (the compiler then
+// pairs them into ds_read2); P (the output gradient dz) is always a plain operand here (PTR = 0).
+template <int TWL, int QTR>
 __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int splits, int steps_per_split) {
-  constexpr int QROWS = WG_PIX + 2;
-  constexpr int STAGE = (WG_PIX + QROWS) * WG_LDS;
+  constexpr int tw_log2 = TWL;
+  constexpr int PTR = 0;
+  constexpr int QROWS_MAX = 48;                       // TW = 4: 8 x 6
+  constexpr int STAGE = (WG_PIX + QROWS_MAX) * WG_LDS;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -431,11 +437,15 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   const int split = lid / (ntiles * 3);
   const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
 
-  const int Ptot = p.NB * p.Hp * p.Wp;
-  const int pix_begin = split * steps_per_split * WG_PIX;
-  int pix_end = pix_begin + steps_per_split * WG_PIX;
-  if (pix_end > Ptot) pix_end = Ptot;
-  const int nsteps = pix_end > pix_begin ? (pix_end - pix_begin) / WG_PIX : 0;   // Ptot % 32 == 0 here
+  constexpr int TW = 1 << tw_log2, TH = WG_PIX >> tw_log2, QW = TW + 2;
+  constexpr int QROWS = TH * QW;
+  const int bx = p.Wp >> tw_log2, by = (p.Hp + TH - 1) / TH;      // blocks per image row / column
+  const int steps_img = bx * by;
+  const int steps_total = p.NB * steps_img;
+  const int step_begin = split * steps_per_split;
+  int step_end = step_begin + steps_per_split;
+  if (step_end > steps_total) step_end = steps_total;
+  const int nsteps = step_end > step_begin ? step_end - step_begin : 0;
 
   f32x16 acc[3];
 #pragma unroll
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
   const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
   const unsigned OOB = 0x80000000u;
+  const int Ptot = p.NB * p.Hp * p.Wp;
   const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, Ptot * Mch * 4,
                                                                         0x00020000);
   const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0,
@@ -468,21 +479,39 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
   const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 
-  // wave-uniform position of the NEXT step to load: image n, row py, first column px0 (px0 % 32 == 0)
-  int sn = pix_begin / (p.Hp * p.Wp);
-  int srem = pix_begin - sn * (p.Hp * p.Wp);
-  int spy = srem / p.Wp, spx0 = srem - spy * p.Wp;
-  // per-thread constants: halo rows j = spx, spx + 16 and (threads with spx < 2) 32 + spx; column j <-> qx = px0 - pad + j
-  const unsigned pv[2] = {(unsigned)spx * mC4 + (unsigned)(mvalid ? mc : 0) * 4u,
-                          (unsigned)(spx + 16) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u};
-  const int qj[3] = {spx, spx + 16, spx + 32};
-  const bool third = spx < 2;
+  // wave-uniform position of the NEXT block to load: image sn, first row spy, first column spx0
+  int sn = step_begin / steps_img;
+  const int srem0 = step_begin - sn * steps_img;
+  int spy = (srem0 / bx) * TH, spx0 = (srem0 - (srem0 / bx) * bx) * TW;
+  // per-thread constants.  P rows k = spx, spx + 16 (pixel (k / TW, k % TW) of the block); Q slab rows s = spx, spx + 16,
+  // spx + 32 (halo position (s / QW, s % QW), column qx = px0 - pad + s % QW)
+  int pr[2], pcol[2];
+  unsigned pv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = spx + 16 * i;
+    pr[i] = k >> tw_log2; pcol[i] = k & (TW - 1);
+    pv[i] = (unsigned)(pr[i] * p.Wp + pcol[i]) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
+  }
+  int qr[3], qj[3];
+  unsigned qv[3];
+  bool qlive[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int sidx = spx + 16 * i;
+    qlive[i] = sidx < QROWS;
+    qr[i] = sidx / QW; qj[i] = sidx - qr[i] * QW;
+    qv[i] = (unsigned)(qr[i] * p.Wq + qj[i]) * qC4 + qcl4;
+  }
+  // LDS float offset of the B fragment of pixel k = 2 kk + lh: slab row (k / TW) * QW + k % TW.  TW >= 2, so k and k - lh
+  // lie in the same block row: offset = compile-time part (kk) + lane part (lh, wn, li)
+  const int blane = lh * WG_LDS + wn * 32 + li;
 
   float4 rp[2], rq[3];
-  float pm, qm[3];
+  float pm[2], qm[3];
 
-  // per-sample (Group/InstanceNorm) tables: a 32-pixel step lies in ONE image (H*W % 32 == 0, host-checked), so the
-  // tables of the step are wave-uniform in n and are re-read only when the image changes
+  // per-sample (Group/InstanceNorm) tables: a block lies in ONE image, so the tables of the step are wave-uniform in n
+  // and are re-read only when the image changes
   const bool p_ps = PTR && p.P.scale && p.P.ss != 0;
   const bool q_ps = QTR && qs.scale && qs.ss != 0;
   int tab_n = -1;
@@ -500,32 +529,29 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
         qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
       }
     }
-    const unsigned psoff = (unsigned)(pix_begin + step * WG_PIX) * mC4;          // scalar, P rows are consecutive pixels
-    const bool pok = live & mvalid;
+    const unsigned psoff = (unsigned)((sn * p.Hp + spy) * p.Wp + spx0) * mC4;    // scalar: first pixel of the block
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const bool pok = live & mvalid & (spy + pr[i] < p.Hp);                     // rows below the image: zeros
       const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv[i] : OOB, psoff, 0));
       rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+      if (PTR) pm[i] = pok ? 1.f : 0.f;
     }
-    if (PTR) pm = pok ? 1.f : 0.f;
-    const int qy = spy + ky - p.pad;                                             // scalar
-    const bool yok = live & (qy >= 0) & (qy < p.Hq);
-    const int qx0 = spx0 - p.pad;                                                // scalar
-    const unsigned sb = (unsigned)(((sn * p.Hq + qy) * p.Wq + qx0) * (int)qC4) + qcl4;   // scalar, wraps by design
+    const int qy0 = spy + ky - p.pad, qx0 = spx0 - p.pad;                        // scalar: halo origin
+    const unsigned sb = (unsigned)(((sn * p.Hq + qy0) * p.Wq + qx0) * (int)qC4);  // scalar, wraps by design
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i < 2 || third) {
-        const int qx = qx0 + qj[i];
-        const bool ok = yok & qvalid & (qx >= 0) & (qx < p.Wq);
-        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rsq, ok ? sb + (unsigned)qj[i] * qC4 : OOB, 0, 0));
+      if (i < 2 || qlive[i]) {
+        const int qy = qy0 + qr[i], qx = qx0 + qj[i];
+        const bool ok = live & qvalid & qlive[i] & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? sb + qv[i] : OOB, 0, 0));
         rq[i] = make_float4(q[0], q[1], q[2], q[3]);
         if (QTR) qm[i] = ok ? 1.f : 0.f;
       }
     }
-    // advance the scalar position by one step (rows are multiples of 32 pixels long)
-    spx0 += WG_PIX;
-    if (spx0 >= p.Wp) { spx0 = 0; spy += 1; if (spy >= p.Hp) { spy = 0; sn += 1; } }
+    // advance the scalar position by one block
+    spx0 += TW;
+    if (spx0 >= p.Wp) { spx0 = 0; spy += TH; if (spy >= p.Hp) { spy = 0; sn += 1; } }
   };
 
   auto xf = [&](float4 v, const float4& sc, const float4& sh, float m, int act, float lo, int tr) -> float4 {
@@ -541,12 +567,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       *reinterpret_cast<float4*>(stage + (spx + 16 * i) * WG_LDS + sc4 * 4) =
-          xf(rp[i], psc, psh, PTR ? pm : 1.f, p.P.act, plo, PTR);
+          xf(rp[i], psc, psh, PTR ? pm[i] : 1.f, p.P.act, plo, PTR);
     float* qst = stage + WG_PIX * WG_LDS;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (i < 2 || third)
-        *reinterpret_cast<float4*>(qst + qj[i] * WG_LDS + sc4 * 4) =
+      if (i < 2 || qlive[i])
+        *reinterpret_cast<float4*>(qst + (spx + 16 * i) * WG_LDS + sc4 * 4) =
             xf(rq[i], qsc, qsh, QTR ? qm[i] : 1.f, qs.act, qlo, QTR);
   };
 
@@ -559,7 +585,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   for (int step = 0; step < nsteps; ++step) {
     issue(step + 1);
     const float* st = lds + buf * STAGE;
-    const float* qst = st + WG_PIX * WG_LDS;
+    const float* qst = st + WG_PIX * WG_LDS + blane;
     float a[16];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WG_LDS + wm * 32 + li];
@@ -567,7 +593,8 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
     for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        const float b = qst[(2 * kk + lh + kx) * WG_LDS + wn * 32 + li];   // column px + kx - pad of the halo slab
+        constexpr int dummy = 0; (void)dummy;
+        const float b = qst[((((2 * kk) >> tw_log2) * QW + ((2 * kk) & (TW - 1))) + kx) * WG_LDS];   // column + kx of the slab
         acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
       }
     }
@@ -632,10 +659,56 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Which kernel a launch goes to (shared by the split-K plan and the launcher): 2 = halo (pixel blocks), 1 = fast (linear
+// 32-pixel steps), 0 = generic.
+struct WgradSel { int kind, tw_log2, ptr, qtr; bool generic_act, per_sample; };
+
+static WgradSel wgrad_select(const MsegWgrad& p) {
+  WgradSel w;
+  auto tr_of = [](const MsegSrc& s) {
+    if (s.act == MSEG_ACT_NONE && !s.scale) return 0;
+    return (s.act == MSEG_ACT_NONE || s.act == MSEG_ACT_RELU) ? 1 : 2;
+  };
+  w.ptr = tr_of(p.P);
+  w.qtr = 0;
+  w.generic_act = (p.P.act != MSEG_ACT_NONE && p.P.act != MSEG_ACT_RELU);
+  w.per_sample = (p.P.scale && p.P.ss != 0);
+  for (int i = 0; i < p.nq; ++i) {
+    const int v = tr_of(p.Q[i]);
+    if (v > w.qtr) w.qtr = v;
+    if (p.Q[i].act != MSEG_ACT_NONE && p.Q[i].act != MSEG_ACT_RELU) w.generic_act = true;
+    if (p.Q[i].scale && p.Q[i].ss != 0) w.per_sample = true;
+  }
+  // halo shape: 3x3 stride-1 conv, plain P (the output gradient), row length divisible by 4 -> TH x TW pixel blocks with
+  // TW = largest power of two <= 32 dividing W; used when at most 20 % of the block rows hang over the image bottom
+  w.tw_log2 = 5;
+  bool halo = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.Hq == p.Hp && p.Wq == p.Wp && (p.Wp % 4) == 0 && w.ptr == 0;
+  if (halo) {
+    while ((p.Wp & ((1 << w.tw_log2) - 1)) != 0) --w.tw_log2;
+    const int TH = WG_PIX >> w.tw_log2;
+    halo = (long long)p.Hp * 5 >= (long long)((p.Hp + TH - 1) / TH) * TH * 4;
+  }
+  // fast-path preconditions: operands < 2 GiB (32-bit buffer offsets), concat boundary on a 64-channel tile, and for
+  // per-sample (Group/InstanceNorm) tables a K-step that cannot straddle two images (always true for pixel blocks)
+  const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
+  bool fast = (!w.per_sample || halo || ((long long)p.Hp * p.Wp) % WG_PIX == 0) &&
+              Ptot64 * p.P.C * 4 < 0x80000000LL && (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
+  for (int i = 0; i < p.nq; ++i)
+    if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) fast = false;
+  if (p.nq > 1 && (p.Q[0].C % 64)) fast = false;
+  w.kind = fast ? (halo ? 2 : 1) : 0;
+  return w;
+}
+
 static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   const long long Ptot = (long long)p.NB * p.Hp * p.Wp;
   if (Ptot <= 0) return MSEG_EINVAL;
-  const long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
+  long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
+  const WgradSel sel = wgrad_select(p);
+  if (sel.kind == 2) {
+    const int TH = WG_PIX >> sel.tw_log2;
+    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks (wgrad_halo_kernel)
+  }
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   const int per_split_wgs = tiles * p.KH;
   // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs
@@ -679,22 +752,11 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
   if (p.phase != 2) {
-    bool generic = (p.P.act != MSEG_ACT_NONE && p.P.act != MSEG_ACT_RELU);
-    bool per_sample = (p.P.scale && p.P.ss != 0);
-    for (int i = 0; i < p.nq; ++i) {
-      if (p.Q[i].act != MSEG_ACT_NONE && p.Q[i].act != MSEG_ACT_RELU) generic = true;
-      if (p.Q[i].scale && p.Q[i].ss != 0) per_sample = true;
-    }
+    const WgradSel sel = wgrad_select(p);
+    const bool generic = sel.generic_act, per_sample = sel.per_sample;
+    const int ptr = sel.ptr, qtr = sel.qtr, tw_log2 = sel.tw_log2;
     const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)p.KH), block(256);
-    // fast path preconditions (see wgrad_fast_kernel)
-    const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
-    // per-sample tables (Group/InstanceNorm) ride the fast paths when a 32-pixel K-step cannot straddle two images
-    bool fast = (!per_sample || ((long long)p.Hp * p.Wp) % WG_PIX == 0) && Ptot64 * p.P.C * 4 < 0x80000000LL &&
-                (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
-    for (int i = 0; i < p.nq; ++i)
-      if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) fast = false;
-    if (p.nq > 1 && (p.Q[0].C % 64)) fast = false;
-    if (fast) {
+    if (sel.kind != 0) {
       static bool ident_ready[64] = {false};
       int devid = 0;
       if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
@@ -703,18 +765,10 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
         MSEG_LAUNCH_CHECK();
         ident_ready[devid] = true;
       }
-      auto tr_of = [](const MsegSrc& s) {
-        if (s.act == MSEG_ACT_NONE && !s.scale) return 0;
-        return (s.act == MSEG_ACT_NONE || s.act == MSEG_ACT_RELU) ? 1 : 2;
-      };
-      const int ptr = tr_of(p.P);
-      int qtr = 0;
-      for (int i = 0; i < p.nq; ++i) { const int v = tr_of(p.Q[i]); if (v > qtr) qtr = v; }
-      const bool halo = p.KH == 3 && p.KW == 3 && p.stride == 1 && (p.Wp % WG_PIX) == 0 && p.Hq == p.Hp && p.Wq == p.Wp;
-      if (halo) {
-#define MSEG_WH(P_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<P_, Q_>), grid, block, 0, st, p, splits, sps)
-#define MSEG_WH_Q(P_) do { if (qtr == 0) MSEG_WH(P_, 0); else if (qtr == 1) MSEG_WH(P_, 1); else MSEG_WH(P_, 2); } while (0)
-        if (ptr == 0) MSEG_WH_Q(0); else if (ptr == 1) MSEG_WH_Q(1); else MSEG_WH_Q(2);
+      if (sel.kind == 2) {
+#define MSEG_WH(T_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WH_Q(T_) do { if (qtr == 0) MSEG_WH(T_, 0); else if (qtr == 1) MSEG_WH(T_, 1); else MSEG_WH(T_, 2); } while (0)
+        if (tw_log2 == 5) MSEG_WH_Q(5); else if (tw_log2 == 4) MSEG_WH_Q(4); else if (tw_log2 == 3) MSEG_WH_Q(3); else MSEG_WH_Q(2);
 #undef MSEG_WH_Q
 #undef MSEG_WH
         MSEG_LAUNCH_CHECK();

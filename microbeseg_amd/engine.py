@@ -140,14 +140,29 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok
     return "igemm_kernel<128, %d, %s, %s>" % (bn, "true" if per_sample else "false", "true" if generic else "false")
 
 
+def _wgrad_halo_shape(Hp, Wp, Hq, Wq, KW, stride):
+    """mirror of wgrad_halo_shape in csrc/wgrad.hip"""
+    if not (KW == 3 and stride == 1 and Hq == Hp and Wq == Wp and Wp % 4 == 0):
+        return False
+    tw = 32
+    while Wp % tw:
+        tw //= 2
+    th = 32 // tw
+    return Hp * 5 >= ((Hp + th - 1) // th) * th * 4
+
+
 def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
-    fast = ((not per_sample) or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and \
+    halo = _wgrad_halo_shape(Hp, Wp, Hq, Wq, KW, stride) and _tr_of(P) == 0
+    fast = ((not per_sample) or halo or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and \
         all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
     fast = fast and (len(Qs) == 1 or Qs[0].C % 64 == 0)
-    if fast and KW == 3 and stride == 1 and Wp % 32 == 0 and Hq == Hp and Wq == Wp:
-        return "wgrad_halo_kernel<%d, %d>" % (_tr_of(P), max(_tr_of(s) for s in Qs))
+    if fast and halo:
+        twl = 5
+        while Wp % (1 << twl):
+            twl -= 1
+        return "wgrad_halo_kernel<%d, %d>" % (twl, max(_tr_of(s) for s in Qs))
     if fast:
         return "wgrad_fast_kernel<%d, %d, %d>" % (KW, _tr_of(P), max(_tr_of(s) for s in Qs))
     return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
