@@ -207,7 +207,17 @@ class EvalWorker(QObject):
                                                  num_workers=getattr(self, 'num_workers', num_workers))
         lib = _lib.load()
         net.eval()
+        # the reference switches autograd off globally here (eval.py:356); this build restores the caller's mode
+        grad_mode = torch.is_grad_enabled()
         torch.set_grad_enabled(False)
+        try:
+            self._inference_loop(lib, net, dataloader, dataset, label_type, ths, batch_size, device, path_model, save_raw,
+                                 eval_progress)
+        finally:
+            torch.set_grad_enabled(grad_mode)
+
+    def _inference_loop(self, lib, net, dataloader, dataset, label_type, ths, batch_size, device, path_model, save_raw,
+                        eval_progress):
         for i, sample in enumerate(dataloader):
             if i % 5 == 0:
                 QCoreApplication.processEvents()

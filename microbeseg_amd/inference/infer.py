@@ -80,13 +80,13 @@ class InferWorker(QObject):
         :return: instance mask, np.uint16, shape of the un-padded frame.
         """
         self.net.eval()
-        torch.set_grad_enabled(False)
         # 2 * (f32(img) - min) / (max - min) - 1, same operation order and scalar types as infer.py:346-348
         img_batch = 2 * (img.astype(np.float32) - min_val) / (max_val - min_val) - 1
         img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
         img_batch = img_batch.to(self.device)
         try:
-            return self._predict(img_batch, pads)
+            with torch.no_grad():   # the reference disables autograd globally (infer.py:343); here only for the call
+                return self._predict(img_batch, pads)
         except RuntimeError:   # load-bearing in the reference: zero mask instead of a crash (infer.py:354-356)
             self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
             return np.zeros_like(img, dtype=np.uint16)[pads[0]:, pads[1]:]
@@ -132,7 +132,6 @@ class InferWorker(QObject):
             return results
 
         self.net.eval()
-        torch.set_grad_enabled(False)
         side = torch.cuda.Stream(device=self.device)
         pending = []      # (frame index, pinned host mask, event on the side stream)
 
@@ -143,7 +142,7 @@ class InferWorker(QObject):
                 results[f] = host.numpy().view(np.uint16)
             self.progress.emit(int(100 * (f + 1) / len(img)))
 
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), torch.no_grad():
             for frame in range(len(img)):
                 if self.stop_inference:
                     break
