@@ -88,11 +88,12 @@ def broadcast_buffers(module, src=0, group=None):
     for dtype, group_bufs in by_dtype.items():
         flat = torch.cat([b.reshape(-1) for b in group_bufs])
         dist.broadcast(flat, src=src, group=group)
-        off = 0
+        off, views = 0, []
         for b in group_bufs:
             n = b.numel()
-            b.copy_(flat[off:off + n].view_as(b))
+            views.append(flat[off:off + n].view_as(b))
             off += n
+        torch._foreach_copy_(group_bufs, views)       # one multi-tensor launch instead of one copy per buffer
 
 
 def broadcast_parameters(module, src=0, group=None):
