@@ -560,6 +560,153 @@ __global__ void pp_flood_serial_kernel(const float* __restrict__ img, const uint
   counters[C_SCRATCH] = 1;                               // status bit 0: exact serial path was used
 }
 
+// Exact flood of a CONSTANT image (boundary method: watershed(image=mask, ...), every key ties on the value).
+// The reference's heap then orders entries by age alone:
+//   phase 1  all initial markers carry age 0; they pop first, in an order that only the binary heap's internal layout
+//            defines (equal keys are neither swapped on push nor on pop, pushed neighbours with larger keys sink through
+//            them).  That order — and with it the order in which the first ring of neighbours is pushed — has to be
+//            replayed on the very same heap: one lane, exactly the code of the generic flood;
+//   phase 2  every later entry has a unique, increasing age: the heap degenerates to a FIFO queue and the flood is a
+//            breadth-first search in queue order.  It is replayed level by level by the whole workgroup: a level's
+//            entries claim their unlabelled neighbours with atomicMin((position in level) * 4 + neighbour slot) — the
+//            smallest key is the entry the serial flood would have reached first — and the winners are appended to the
+//            queue in (position, slot) order through a block-wide prefix sum, which is the serial push order.
+// One workgroup of 1024 lanes (a frame's frontier is some 10^4 pixels per level); phase 1 is the serial remainder.
+#define PPC_THREADS 1024
+__device__ __forceinline__ int ppc_block_scan(int* sh, int tid, int v, int* total) {   // exclusive prefix of v over lanes
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < PPC_THREADS; o <<= 1) {
+    const int t = tid >= o ? sh[tid - o] : 0;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  const int incl = sh[tid];
+  *total = sh[PPC_THREADS - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_kernel(
+    const float* __restrict__ img, const uint8_t* __restrict__ mask, const int32_t* __restrict__ markers,
+    unsigned long long* __restrict__ hkey, uint32_t* __restrict__ hidx, uint32_t* __restrict__ queue,
+    uint32_t* __restrict__ claim, int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+  __shared__ int sh_scan[PPC_THREADS];
+  __shared__ int sh_head, sh_tail;
+  if (!counters[C_SERIAL]) return;                       // uniform for the whole workgroup
+  const size_t n = (size_t)H * W;
+  const int tid = threadIdx.x;
+  // labels start as the markers; marker pixels are listed in raster order at the END of the queue buffer (the queue
+  // itself never holds a marker, so it stays below n - M)
+  const size_t chunk = (n + PPC_THREADS - 1) / PPC_THREADS;
+  const size_t c0 = (size_t)tid * chunk, c1 = (c0 + chunk < n) ? c0 + chunk : n;
+  int mine = 0;
+  for (size_t i = c0; i < c1; ++i) {
+    const int m = markers[i];
+    out[i] = m;
+    claim[i] = 0xffffffffu;
+    mine += (m != 0);
+  }
+  int M = 0;
+  int moff = ppc_block_scan(sh_scan, tid, mine, &M);
+  uint32_t* mlist = queue + (n - (size_t)M);
+  for (size_t i = c0; i < c1; ++i)
+    if (markers[i] != 0) mlist[moff++] = (uint32_t)i;
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    // ---- phase 1: the age-0 markers through the reference heap ----------------------------------------------------
+    PPHeap h;
+    h.key = hkey; h.idx = hidx; h.n = 0; h.taint = 0;
+    for (int i = 0; i < M; ++i) { const uint32_t j = mlist[i]; pp_push(h, pp_key(img[j], 0u), j); }
+    unsigned age = 0;
+    int qn = 0;
+    for (int m_left = M; m_left > 0; --m_left) {         // only age-0 entries can pop while one of them is left
+      unsigned long long k; uint32_t e;
+      pp_pop(h, k, e);
+      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+      const int lab = out[e];
+#define PPC_VISIT(COND, J)                                                       \
+      if (COND) {                                                                \
+        const uint32_t j = (J);                                                  \
+        if (mask[j] && out[j] == 0) {                                            \
+          out[j] = lab;                                                          \
+          pp_push(h, pp_key(img[j], ++age), j);                                  \
+          queue[qn++] = j;                                                       \
+        }                                                                        \
+      }
+      PPC_VISIT(y > 0, e - W)
+      PPC_VISIT(x > 0, e - 1)
+      PPC_VISIT(x + 1 < W, e + 1)
+      PPC_VISIT(y + 1 < H, e + W)
+#undef PPC_VISIT
+    }
+    sh_head = 0; sh_tail = qn;
+    counters[C_SCRATCH] = 1;                             // status bit 0: the exact serial phase was used
+    __threadfence_block();
+  }
+  __syncthreads();
+  // ---- phase 2: breadth-first search in queue order, level by level ----------------------------------------------------
+  // values written by other waves of the workgroup are read with agent-scope loads (past the per-CU vector cache)
+#define PPC_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  for (;;) {
+    const int head = sh_head, tail = sh_tail;
+    const int cnt = tail - head;
+    if (cnt <= 0) break;                                 // uniform exit: every lane reads the same shared values
+    const int per = (cnt + PPC_THREADS - 1) / PPC_THREADS;
+    const int b = tid * per < cnt ? tid * per : cnt, e_end = (b + per < cnt) ? b + per : cnt;
+    // claim: position in level * 4 + neighbour slot (up, left, right, down = the reference's neighbour order)
+    for (int q = b; q < e_end; ++q) {
+      const uint32_t e = PPC_LD(&queue[head + q]);
+      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+      const unsigned key = (unsigned)q * 4u;
+      if (y > 0 && mask[e - W] && PPC_LD(&out[e - W]) == 0) atomicMin(&claim[e - W], key);
+      if (x > 0 && mask[e - 1] && PPC_LD(&out[e - 1]) == 0) atomicMin(&claim[e - 1], key + 1u);
+      if (x + 1 < W && mask[e + 1] && PPC_LD(&out[e + 1]) == 0) atomicMin(&claim[e + 1], key + 2u);
+      if (y + 1 < H && mask[e + W] && PPC_LD(&out[e + W]) == 0) atomicMin(&claim[e + W], key + 3u);
+    }
+    __threadfence();
+    __syncthreads();
+    // winners of this lane's (contiguous) part of the level.  A claim value equal to this entry's key identifies the
+    // unique winner of a pixel; out == 0 rules out stale claims of pixels labelled in earlier levels.
+    int wins = 0;
+    for (int q = b; q < e_end; ++q) {
+      const uint32_t e = PPC_LD(&queue[head + q]);
+      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+      const unsigned key = (unsigned)q * 4u;
+      if (y > 0 && mask[e - W] && PPC_LD(&claim[e - W]) == key && PPC_LD(&out[e - W]) == 0) ++wins;
+      if (x > 0 && mask[e - 1] && PPC_LD(&claim[e - 1]) == key + 1u && PPC_LD(&out[e - 1]) == 0) ++wins;
+      if (x + 1 < W && mask[e + 1] && PPC_LD(&claim[e + 1]) == key + 2u && PPC_LD(&out[e + 1]) == 0) ++wins;
+      if (y + 1 < H && mask[e + W] && PPC_LD(&claim[e + W]) == key + 3u && PPC_LD(&out[e + W]) == 0) ++wins;
+    }
+    int total = 0;
+    int pos = tail + ppc_block_scan(sh_scan, tid, wins, &total);
+    // append in (position, slot) order and label: only the winner of a pixel passes its test, so it is the only writer
+    for (int q = b; q < e_end; ++q) {
+      const uint32_t e = PPC_LD(&queue[head + q]);
+      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+      const unsigned key = (unsigned)q * 4u;
+      const int lab = PPC_LD(&out[e]);
+#define PPC_TAKE(COND, J, K)                                                     \
+      if (COND) {                                                                \
+        const uint32_t j = (J);                                                  \
+        if (mask[j] && PPC_LD(&claim[j]) == (K) && PPC_LD(&out[j]) == 0) { queue[pos++] = j; out[j] = lab; }  \
+      }
+      PPC_TAKE(y > 0, e - W, key)
+      PPC_TAKE(x > 0, e - 1, key + 1u)
+      PPC_TAKE(x + 1 < W, e + 1, key + 2u)
+      PPC_TAKE(y + 1 < H, e + W, key + 3u)
+#undef PPC_TAKE
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) { sh_head = tail; sh_tail = tail + total; }
+    __syncthreads();
+  }
+#undef PPC_LD
+}
+
 __global__ void pp_finalize_kernel(const int32_t* __restrict__ out, uint16_t* __restrict__ labels, size_t n,
                                    const int32_t* __restrict__ counters, int32_t* __restrict__ n_inst,
                                    int32_t* __restrict__ status) {
@@ -630,8 +777,15 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
                      (const int32_t*)w.markers, (const int32_t*)w.mlab, (const int32_t*)w.clist,
                      (const int32_t*)w.hoff, (const int32_t*)w.bymin, (const int32_t*)w.bymax,
                      (const int32_t*)w.bxmin, (const int32_t*)w.bxmax, w.hkey, w.hidx, w.out, H, W, w.counters);
-  hipLaunchKernelGGL(pp_flood_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask,
-                     (const int32_t*)w.markers, w.hkey, w.hidx, w.out, H, W, w.counters);
+  if (force_serial) {
+    // constant image (boundary method): serial heap phase for the age-0 markers, then an ordered parallel BFS
+    hipLaunchKernelGGL(pp_flood_const_kernel, dim3(1), dim3(PPC_THREADS), 0, st, img, (const uint8_t*)w.mask,
+                       (const int32_t*)w.markers, w.hkey, w.hidx, (uint32_t*)w.clist, (uint32_t*)w.hoff, w.out, H, W,
+                       w.counters);
+  } else {
+    hipLaunchKernelGGL(pp_flood_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask,
+                       (const int32_t*)w.markers, w.hkey, w.hidx, w.out, H, W, w.counters);
+  }
   hipLaunchKernelGGL(pp_finalize_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.out, labels, n,
                      (const int32_t*)w.counters, n_inst, status);
   MSEG_LAUNCH_CHECK();
