@@ -127,3 +127,23 @@ def test_tie_stress_fast_path_stays_exact(levels, pp):
     if levels >= (1 << 11):
         assert parallel_frames >= n_frames // 2, f"only {parallel_frames}/{n_frames} frames stayed on the parallel path"
         assert tied_parallel > 0, "no frame with tied seed values went through the parallel path"
+
+
+@pytest.mark.parametrize("H,W,n,seed", [(200, 260, 60, 1), (384, 512, 260, 2), (97, 131, 25, 3)])
+def test_boundary_postprocessing_matches_oracle_random(H, W, n, seed, pp):
+    """Boundary method on random frames with leaky boundaries (several seeds per mask component, so labels meet inside
+    components and every tie is decided by the age order): serial marker phase + ordered parallel BFS vs the C oracle."""
+    from microbeseg_amd.utils import synth
+    from oracle import postproc_ref
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    cell, border = synth.synth_prediction_maps(rng, H, W, n, rmin=5.0, rmax=12.0)
+    gaps = rng.uniform(0, 1, (H, W)) < 0.35                      # holes in the boundary class -> merged components
+    p1 = np.clip(cell * 2.5, 0, 1) * (1 - np.clip(border * 1.2, 0, 1) * ~gaps)
+    p2 = np.clip(border * 1.2, 0, 1) * (cell > 0.02) * ~gaps
+    p0 = np.clip(1 - p1 - p2, 0.0, 1)
+    probs = np.stack([p0, p1, p2], -1).astype(np.float32)
+    probs /= probs.sum(-1, keepdims=True)
+    got = pp.boundary_postprocessing(probs)
+    want = postproc_ref.boundary_postprocessing(probs)
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+    assert want.max() >= 3
