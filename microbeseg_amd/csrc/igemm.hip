@@ -10,11 +10,17 @@
 //   * torch.cat([up, skip], 1)            (unets.py:373,492,502)         two sources, never materialised
 //   * activation + Batch/Group/InstanceNorm of the *producer* layer      applied while staging A (norm-on-load)
 //
-// Tiling: a workgroup (256 threads = 4 waves) owns BM output pixels x BN output channels; every K-step stages a
-// [BM][32] slab of gathered source pixels (one tap, 32 input channels) and a [BN][32] slab of weights in LDS
-// (row stride 36 floats -> conflict-free ds_read_b128), double buffered (one barrier per K-step); each wave accumulates
-// a 64x64 (BN=128) or 32x64 (BN=64) block as 32x32 MFMA tiles.  The raw global loads of step s+1 are issued before the
-// MFMAs of step s and consumed (activation, scale/shift, ds_write) after them.
+// Three kernels share one epilogue (dispatch: mseg_igemm / igemm_plan at the end of this file):
+//   igemm_halo_kernel  3x3 stride-1 forward + data gradient (the bulk of the FLOPs): 128 pixels x BN channels per
+//                      8-wave workgroup, the input halo of a 32-channel chunk staged and normalised ONCE for all 9 taps,
+//                      two workgroups per CU;
+//   igemm_fast_kernel  everything else that meets the 32-bit-offset preconditions (stride-2 convs and their parity-ordered
+//                      data gradients, ConvTranspose as a 1x1 GEMM, its data gradient): per-tap gather with precomputed
+//                      row offsets / tap masks, 4 waves, 32x32 MFMA tiles;
+//   igemm_kernel       fully general gather (tensors >= 2 GiB, channel counts that are no multiple of 32 at a concat).
+// Common tiling: every K-step consumes a [pixels][32] slab of source pixels (one tap, 32 input channels) and a [BN][32]
+// slab of packed weights from LDS (row stride 36 floats -> conflict-free ds_read_b128); raw global loads of step s+1 are
+// issued before the MFMAs of step s and consumed (activation, scale/shift, ds_write) after them.
 #include "common.h"
 
 #define KC 32
