@@ -69,11 +69,13 @@ class GradBucketer:
         inv = 1.0 / dist.get_world_size(self.group)
         for flat, tensors, work in self.inflight:
             work.wait()
-            off = 0
+            flat.mul_(inv)
+            off, views = 0, []
             for t in tensors:
                 n = t.numel()
-                t.copy_(flat[off:off + n].view_as(t)).mul_(inv)
+                views.append(flat[off:off + n].view_as(t))
                 off += n
+            torch._foreach_copy_(tensors, views)      # one multi-tensor launch per bucket
         self.inflight = []
 
 
