@@ -24,7 +24,8 @@
 #define SCAN_TILE (PP_BLOCK * SCAN_ITEMS)
 
 // counters (int32 slots in workspace)
-enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_COUNT = 16 };
+enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_CONST_M = 7,
+       C_CONST_Q = 12, C_COUNT = 16 };
 
 struct PPWs {
   float* tmp; float* cs;
@@ -572,6 +573,63 @@ __global__ void pp_flood_serial_kernel(const float* __restrict__ img, const uint
 //            smallest key is the entry the serial flood would have reached first — and the winners are appended to the
 //            queue in (position, slot) order through a block-wide prefix sum, which is the serial push order.
 // One workgroup of 1024 lanes (a frame's frontier is some 10^4 pixels per level); phase 1 is the serial remainder.
+// Heap of the serial marker phase with its top levels in LDS: a sift walks one node per level, and the first
+// PPL_TOP = 8191 nodes (13 levels) cost an LDS access instead of a dependent global-memory round trip.
+// Same array layout and the same compare / swap sequence as PPHeap (pp_push / pp_pop above).
+#define PPL_TOP 8192
+struct PPHeapL {
+  unsigned long long* gkey; uint32_t* gidx;     // nodes >= PPL_TOP
+  unsigned long long* lkey; uint32_t* lidx;     // nodes <  PPL_TOP (LDS)
+  int n;
+  __device__ __forceinline__ unsigned long long key(int i) const { return i < PPL_TOP ? lkey[i] : gkey[i]; }
+  __device__ __forceinline__ uint32_t idx(int i) const { return i < PPL_TOP ? lidx[i] : gidx[i]; }
+  __device__ __forceinline__ void set(int i, unsigned long long k, uint32_t ix) {
+    if (i < PPL_TOP) { lkey[i] = k; lidx[i] = ix; } else { gkey[i] = k; gidx[i] = ix; }
+  }
+};
+
+__device__ __forceinline__ void ppl_push(PPHeapL& h, unsigned long long k, uint32_t ix) {
+  int child = h.n++;
+  h.set(child, k, ix);
+  while (child > 0) {
+    const int parent = (child + 1) / 2 - 1;
+    const unsigned long long kp = h.key(parent);
+    if (k < kp) {
+      h.set(child, kp, h.idx(parent));
+      h.set(parent, k, ix);
+      child = parent;
+    } else break;
+  }
+}
+
+// last_k / last_i: the array's last entry (position n - 1), fetched by the caller ahead of time
+__device__ __forceinline__ void ppl_pop(PPHeapL& h, unsigned long long& tk, uint32_t& ti, unsigned long long last_k,
+                                        uint32_t last_i) {
+  tk = h.key(0); ti = h.idx(0);
+  const int n = --h.n;
+  if (n == 0) return;
+  const unsigned long long lk = last_k;
+  const uint32_t li = last_i;
+  h.set(0, lk, li);
+  int i = 0;
+  for (;;) {
+    const int l = 2 * i + 1, r = 2 * i + 2;
+    if (l >= n) break;
+    int smallest = i;
+    unsigned long long ks = lk;                       // key currently at position i is always `last`
+    const unsigned long long kl = h.key(l);
+    if (kl < ks) { smallest = l; ks = kl; }
+    if (r < n) {
+      const unsigned long long kr = h.key(r);
+      if (kr < ks) { smallest = r; ks = kr; }
+    }
+    if (smallest == i) break;
+    h.set(i, ks, h.idx(smallest));
+    h.set(smallest, lk, li);
+    i = smallest;
+  }
+}
+
 #define PPC_THREADS 1024
 __device__ __forceinline__ int ppc_block_scan(int* sh, int tid, int v, int* total) {   // exclusive prefix of v over lanes
   sh[tid] = v;
@@ -588,12 +646,11 @@ __device__ __forceinline__ int ppc_block_scan(int* sh, int tid, int v, int* tota
   return incl - v;
 }
 
-__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_kernel(
-    const float* __restrict__ img, const uint8_t* __restrict__ mask, const int32_t* __restrict__ markers,
-    unsigned long long* __restrict__ hkey, uint32_t* __restrict__ hidx, uint32_t* __restrict__ queue,
-    uint32_t* __restrict__ claim, int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+// kernel 1/3: labels start as the markers; marker pixels listed in raster order
+__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_init_kernel(
+    const int32_t* __restrict__ markers, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
+    int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
   __shared__ int sh_scan[PPC_THREADS];
-  __shared__ int sh_head, sh_tail;
   if (!counters[C_SERIAL]) return;                       // uniform for the whole workgroup
   const size_t n = (size_t)H * W;
   const int tid = threadIdx.x;
@@ -613,41 +670,128 @@ __global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_kernel(
   uint32_t* mlist = queue + (n - (size_t)M);
   for (size_t i = c0; i < c1; ++i)
     if (markers[i] != 0) mlist[moff++] = (uint32_t)i;
-  __threadfence_block();
-  __syncthreads();
-  if (tid == 0) {
-    // ---- phase 1: the age-0 markers through the reference heap ----------------------------------------------------
-    PPHeap h;
-    h.key = hkey; h.idx = hidx; h.n = 0; h.taint = 0;
-    for (int i = 0; i < M; ++i) { const uint32_t j = mlist[i]; pp_push(h, pp_key(img[j], 0u), j); }
-    unsigned age = 0;
-    int qn = 0;
-    for (int m_left = M; m_left > 0; --m_left) {         // only age-0 entries can pop while one of them is left
-      unsigned long long k; uint32_t e;
-      pp_pop(h, k, e);
-      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
-      const int lab = out[e];
-#define PPC_VISIT(COND, J)                                                       \
-      if (COND) {                                                                \
-        const uint32_t j = (J);                                                  \
-        if (mask[j] && out[j] == 0) {                                            \
-          out[j] = lab;                                                          \
-          pp_push(h, pp_key(img[j], ++age), j);                                  \
-          queue[qn++] = j;                                                       \
-        }                                                                        \
-      }
-      PPC_VISIT(y > 0, e - W)
-      PPC_VISIT(x > 0, e - 1)
-      PPC_VISIT(x + 1 < W, e + 1)
-      PPC_VISIT(y + 1 < H, e + W)
-#undef PPC_VISIT
-    }
-    sh_head = 0; sh_tail = qn;
-    counters[C_SCRATCH] = 1;                             // status bit 0: the exact serial phase was used
-    __threadfence_block();
+  if (tid == 0) counters[C_CONST_M] = M;
+}
+
+// kernel 2/3: the age-0 markers through the reference heap — one wavefront.
+// One pop = take the root, move the array's last entry to the root, sift it down.  While that last entry is an age-0
+// marker it ties with everything below it and stays at the root, so a run of pops simply walks the array backwards:
+// root, a[n-1], a[n-2], ...  Most markers are interior pixels of a seed whose neighbours are all labelled already: their
+// pops push nothing and change nothing but the root.  The wavefront therefore looks 64 pops ahead at once — lane u
+// fetches the entry and the neighbour state of the u-th predicted pop — retires the leading pops that neither push a
+// neighbour nor move a pushed (age > 0) entry to the root in one step, and lets lane 0 execute the first pop that does
+// with the reference code.  Same pop / push sequence as the serial flood, ~1/50 of its dependent memory round trips.
+__global__ __launch_bounds__(64) void pp_flood_const_serial_kernel(
+    const float* __restrict__ img, const uint8_t* __restrict__ mask, unsigned long long* __restrict__ hkey,
+    uint32_t* __restrict__ hidx, uint32_t* __restrict__ queue, int32_t* __restrict__ out, int H, int W,
+    int32_t* __restrict__ counters) {
+  __shared__ unsigned long long sh_hkey[PPL_TOP];
+  __shared__ uint32_t sh_hidx[PPL_TOP];
+  __shared__ int sh_n, sh_qn, sh_mleft;
+  __shared__ unsigned sh_age;
+  if (!counters[C_SERIAL]) return;
+  const size_t n = (size_t)H * W;
+  const int lane = threadIdx.x;
+  const int M = counters[C_CONST_M];
+  const uint32_t* mlist = queue + (n - (size_t)M);
+  PPHeapL h;
+  h.gkey = hkey; h.gidx = hidx; h.lkey = sh_hkey; h.lidx = sh_hidx; h.n = 0;
+#define PPC_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  // ---- initial heap: equal keys are never swapped on push, so the array is the marker list in raster order -------------
+  const unsigned long long key0 = M > 0 ? pp_key(img[mlist[0]], 0u) : 0ull;
+  bool all_equal = true;
+  for (int i = lane; i < M; i += 64) {
+    const uint32_t j = mlist[i];
+    const unsigned long long k = pp_key(img[j], 0u);
+    all_equal &= (k == key0);
+    h.set(i, k, j);
   }
+  all_equal = __all(all_equal);
   __syncthreads();
-  // ---- phase 2: breadth-first search in queue order, level by level ----------------------------------------------------
+  if (!all_equal && lane == 0) {                         // not a constant image after all: build it the reference way
+    h.n = 0;
+    for (int i = 0; i < M; ++i) { const uint32_t j = mlist[i]; ppl_push(h, pp_key(img[j], 0u), j); }
+  }
+  if (lane == 0) { sh_n = M; sh_qn = 0; sh_mleft = M; sh_age = 0u; }
+  __syncthreads();
+  // ---- pops -------------------------------------------------------------------------------------------------------------
+  for (;;) {
+    const int n0 = sh_n, m_left = sh_mleft;
+    if (m_left <= 0) break;                              // uniform
+    int B = m_left < 64 ? m_left : 64;
+    if (B > n0) B = n0;
+    // lane u: predicted pop u = root (u = 0) or entry n0 - u; the entry that pop moves to the root is entry n0 - 1 - u
+    const bool act = lane < B;
+    const int ppos = (lane == 0) ? 0 : n0 - lane;
+    const int tpos = n0 - 1 - lane;
+    bool event = false;
+    if (act) {
+      const uint32_t e = h.idx(ppos > 0 ? ppos : 0);
+      // a pushed entry about to reach the root (or already predicted as a pop): the prediction ends here
+      const bool tail_big = (tpos >= 1) && ((unsigned)h.key(tpos) != 0u);
+      const bool self_big = (unsigned)h.key(ppos > 0 ? ppos : 0) != 0u;
+      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+      bool push = false;
+      if (y > 0) push |= mask[e - W] && PPC_LD(&out[e - W]) == 0;
+      if (x > 0) push |= mask[e - 1] && PPC_LD(&out[e - 1]) == 0;
+      if (x + 1 < W) push |= mask[e + 1] && PPC_LD(&out[e + 1]) == 0;
+      if (y + 1 < H) push |= mask[e + W] && PPC_LD(&out[e + W]) == 0;
+      event = push | tail_big | self_big;
+    }
+    const unsigned long long evmask = __ballot(act && event);
+    const int c = evmask ? (__ffsll((long long)evmask) - 1) : B;      // pops 0 .. c-1 are plain root replacements
+    __syncthreads();
+    if (lane == 0) {
+      int nn = n0, ml = m_left;
+      if (c > 0) {                                       // retire them: only the root and the size change
+        nn = n0 - c;
+        if (nn > 0) h.set(0, h.key(nn), h.idx(nn));
+        ml -= c;
+      }
+      h.n = nn;
+      if (c < B) {                                       // the pop that pushes / sinks a pushed entry: reference code
+        unsigned age = sh_age;
+        int qn = sh_qn;
+        unsigned long long k; uint32_t e;
+        ppl_pop(h, k, e, h.n >= 2 ? h.key(h.n - 1) : 0ull, h.n >= 2 ? h.idx(h.n - 1) : 0u);
+        --ml;
+        const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+        const bool nv[4] = {y > 0, x > 0, x + 1 < W, y + 1 < H};
+        const uint32_t nj[4] = {nv[0] ? e - W : e, nv[1] ? e - 1 : e, nv[2] ? e + 1 : e, nv[3] ? e + W : e};
+        const int lab = PPC_LD(&out[e]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (nv[q] && mask[nj[q]] && PPC_LD(&out[nj[q]]) == 0) {
+            const uint32_t j = nj[q];
+            out[j] = lab;
+            ppl_push(h, pp_key(img[j], ++age), j);
+            queue[qn++] = j;
+          }
+        }
+        sh_age = age; sh_qn = qn;
+      }
+      sh_n = h.n; sh_mleft = ml;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (lane == 0) {
+    counters[C_CONST_Q] = sh_qn;
+    counters[C_SCRATCH] = 1;                             // status bit 0: the exact serial phase was used
+  }
+#undef PPC_LD
+}
+
+// kernel 3/3: breadth-first search in queue order, level by level
+__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_bfs_kernel(
+    const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
+    int32_t* __restrict__ out, int H, int W, const int32_t* __restrict__ counters) {
+  __shared__ int sh_scan[PPC_THREADS];
+  __shared__ int sh_head, sh_tail;
+  if (!counters[C_SERIAL]) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) { sh_head = 0; sh_tail = counters[C_CONST_Q]; }
+  __syncthreads();
   // values written by other waves of the workgroup are read with agent-scope loads (past the per-CU vector cache)
 #define PPC_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
   for (;;) {
@@ -779,9 +923,12 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
                      (const int32_t*)w.bxmin, (const int32_t*)w.bxmax, w.hkey, w.hidx, w.out, H, W, w.counters);
   if (force_serial) {
     // constant image (boundary method): serial heap phase for the age-0 markers, then an ordered parallel BFS
-    hipLaunchKernelGGL(pp_flood_const_kernel, dim3(1), dim3(PPC_THREADS), 0, st, img, (const uint8_t*)w.mask,
-                       (const int32_t*)w.markers, w.hkey, w.hidx, (uint32_t*)w.clist, (uint32_t*)w.hoff, w.out, H, W,
-                       w.counters);
+    hipLaunchKernelGGL(pp_flood_const_init_kernel, dim3(1), dim3(PPC_THREADS), 0, st, (const int32_t*)w.markers,
+                       (uint32_t*)w.clist, (uint32_t*)w.hoff, w.out, H, W, w.counters);
+    hipLaunchKernelGGL(pp_flood_const_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask, w.hkey,
+                       w.hidx, (uint32_t*)w.clist, w.out, H, W, w.counters);
+    hipLaunchKernelGGL(pp_flood_const_bfs_kernel, dim3(1), dim3(PPC_THREADS), 0, st, (const uint8_t*)w.mask,
+                       (uint32_t*)w.clist, (uint32_t*)w.hoff, w.out, H, W, (const int32_t*)w.counters);
   } else {
     hipLaunchKernelGGL(pp_flood_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask,
                        (const int32_t*)w.markers, w.hkey, w.hidx, w.out, H, W, w.counters);
