@@ -746,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-    hpix[j] = (img * H + iy) * W + ix;
+    hpix[j] = iy * W + ix;                           // pixel index inside the image (the descriptors are per image)
     hvalid |= (unsigned)ok << j;
   }
   // per-lane LDS row of the MFMA A rows (tile pixel -> halo coordinates of tap (0,0))
@@ -768,11 +768,15 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   const int nchunks = (p.Cin + KC - 1) / KC;
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0,
-                                                                        M * p.src[0].C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr), 0, M * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * 4,
-      0x00020000);
+  // buffer descriptors of THIS tile's image: 32-bit offsets then only have to span one image (< 2 GiB, host-checked),
+  // whatever the batch size — the tensor as a whole may be far larger
+  const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
+  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
+                                                                        H * W * p.src[0].C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
+                                                                        H * W * C1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 4, 0x00020000);
   unsigned wvoff[Cfg::BROWS];
@@ -949,19 +953,23 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long tiles = ((M + BMv - 1) / BMv) * ((p.Ngemm + BNv - 1) / BNv);
   if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
   const dim3 grid((unsigned)tiles), block(256);
-  // fast path preconditions (see igemm_fast_kernel)
+  // fast path preconditions (see igemm_fast_kernel): 32-bit buffer offsets over the WHOLE operand (< 2 GiB)
   bool fast = (p.mode == MSEG_MODE_CONV) || (p.stride == 1) ||
               (p.morder == MSEG_MORDER_PARITY && (M % (4 * BMv)) == 0);   // s2 dgrad: parity-uniform tiles
-  bool plain = true;
+  bool plain = true, image_fits = true;
   for (int i = 0; i < p.nsrc; ++i) {
     if ((long long)p.NB * p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) fast = false;
+    if ((long long)p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) image_fits = false;
     if (p.src[i].act != MSEG_ACT_NONE || p.src[i].scale) plain = false;
   }
-  if ((long long)p.KH * p.KW * p.Npad * p.Kpad * 4 >= 0x80000000LL) fast = false;
-  if (p.KH > 4 || p.KW > 4) fast = false;                            // packed tap list: 2 bits per tap coordinate
-  if (p.nsrc > 1 && (p.src[0].C % KC)) fast = false;
-  // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient)
-  if (fast && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
+  bool common = true;                                                // shared by the fast and the halo kernel
+  if ((long long)p.KH * p.KW * p.Npad * p.Kpad * 4 >= 0x80000000LL) common = false;
+  if (p.KH > 4 || p.KW > 4) common = false;                          // packed tap list: 2 bits per tap coordinate
+  if (p.nsrc > 1 && (p.src[0].C % KC)) common = false;
+  fast = fast && common;
+  // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient).  Its descriptors are
+  // per image, so only ONE IMAGE of each operand has to stay below 2 GiB: any batch size keeps the fast path.
+  if (common && image_fits && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
       p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0) {
     int tw_log2 = 6;
     while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 64 dividing W

@@ -462,11 +462,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
   const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
   const unsigned OOB = 0x80000000u;
-  const int Ptot = p.NB * p.Hp * p.Wp;
-  const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, Ptot * Mch * 4,
-                                                                        0x00020000);
-  const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0,
-                                                                        Ptot * qs.C * 4, 0x00020000);
+  // buffer descriptors of ONE image, re-based whenever the walk enters the next image: 32-bit offsets only have to span
+  // an image (< 2 GiB, host-checked), so the batch size is unlimited
+  const int HWp = p.Hp * p.Wp;
+  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWp * qs.C * 4, 0x00020000);
+  int desc_n = 0;
   float4 psc, psh, qsc, qsh;
   {
     const float* a = (PTR && p.P.scale) ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
@@ -529,7 +530,14 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
         qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
       }
     }
-    const unsigned psoff = (unsigned)((sn * p.Hp + spy) * p.Wp + spx0) * mC4;    // scalar: first pixel of the block
+    if (live && sn != desc_n) {                                                  // scalar: next image
+      desc_n = sn;
+      rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr + (size_t)sn * HWp * Mch), 0, HWp * Mch * 4,
+                                              0x00020000);
+      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWp * qs.C), 0, HWp * qs.C * 4,
+                                              0x00020000);
+    }
+    const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;                  // scalar: first pixel of the block
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool pok = live & mvalid & (spy + pr[i] < p.Hp);                     // rows below the image: zeros
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
       if (PTR) pm[i] = pok ? 1.f : 0.f;
     }
     const int qy0 = spy + ky - p.pad, qx0 = spx0 - p.pad;                        // scalar: halo origin
-    const unsigned sb = (unsigned)(((sn * p.Hq + qy0) * p.Wq + qx0) * (int)qC4);  // scalar, wraps by design
+    const unsigned sb = (unsigned)(qy0 * p.Wq + qx0) * qC4;                      // scalar, wraps by design (halo rows < 0)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i < 2 || qlive[i]) {
@@ -688,14 +696,20 @@ static WgradSel wgrad_select(const MsegWgrad& p) {
     const int TH = WG_PIX >> w.tw_log2;
     halo = (long long)p.Hp * 5 >= (long long)((p.Hp + TH - 1) / TH) * TH * 4;
   }
-  // fast-path preconditions: operands < 2 GiB (32-bit buffer offsets), concat boundary on a 64-channel tile, and for
-  // per-sample (Group/InstanceNorm) tables a K-step that cannot straddle two images (always true for pixel blocks)
+  // fast-path preconditions: 32-bit buffer offsets — the whole operand < 2 GiB for the linear-step kernel, ONE IMAGE of it
+  // for the halo kernel (its descriptors are re-based per image: any batch size); concat boundary on a 64-channel tile;
+  // per-sample (Group/InstanceNorm) tables need a K-step that cannot straddle two images (always true for pixel blocks)
   const long long Ptot64 = (long long)p.NB * p.Hp * p.Wp;
-  bool fast = (!w.per_sample || halo || ((long long)p.Hp * p.Wp) % WG_PIX == 0) &&
-              Ptot64 * p.P.C * 4 < 0x80000000LL && (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
-  for (int i = 0; i < p.nq; ++i)
-    if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) fast = false;
-  if (p.nq > 1 && (p.Q[0].C % 64)) fast = false;
+  const bool pix_ok = (Ptot64 + 2048LL * WG_PIX) < 0x7fffffffLL;
+  bool whole_fits = Ptot64 * p.P.C * 4 < 0x80000000LL, image_fits = (long long)p.Hp * p.Wp * p.P.C * 4 < 0x80000000LL;
+  for (int i = 0; i < p.nq; ++i) {
+    if ((long long)p.NB * p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) whole_fits = false;
+    if ((long long)p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) image_fits = false;
+  }
+  const bool concat_ok = !(p.nq > 1 && (p.Q[0].C % 64));
+  halo = halo && image_fits && pix_ok && concat_ok;
+  const bool fast = halo || (whole_fits && pix_ok && concat_ok &&
+                             (!w.per_sample || ((long long)p.Hp * p.Wp) % WG_PIX == 0));
   w.kind = fast ? (halo ? 2 : 1) : 0;
   return w;
 }

@@ -127,10 +127,11 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok
     bn = 128 if Ngemm > 64 else 64
     per_sample = any(s.scale and s.ss != 0 for s in srcs)
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in srcs)
-    fast = (mode == MODE_CONV or stride == 1 or parity_tiles) and KH <= 4 and KW <= 4
-    fast = fast and all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs) and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31
-    fast = fast and (len(srcs) == 1 or srcs[0].C % 32 == 0)
-    if fast and halo_ok:
+    common = KH <= 4 and KW <= 4 and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
+    fast = common and (mode == MODE_CONV or stride == 1 or parity_tiles) and \
+        all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+    # the halo kernel's buffer descriptors are per image: only one image of an operand has to stay below 2 GiB
+    if common and halo_ok and all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs):
         tr = max(_tr_of(s) for s in srcs)
         return "igemm_halo_kernel<%d, %d>" % (bn, 0 if tr == 0 else (2 if generic else 1))
     if fast:
@@ -155,9 +156,10 @@ def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
     halo = _wgrad_halo_shape(Hp, Wp, Hq, Wq, KW, stride) and _tr_of(P) == 0
-    fast = ((not per_sample) or halo or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and \
-        all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
-    fast = fast and (len(Qs) == 1 or Qs[0].C % 64 == 0)
+    concat_ok = len(Qs) == 1 or Qs[0].C % 64 == 0
+    halo = halo and concat_ok and Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
+    fast = halo or (concat_ok and ((not per_sample) or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and
+                    all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs))
     if fast and halo:
         twl = 5
         while Wp % (1 << twl):

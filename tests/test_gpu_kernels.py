@@ -306,3 +306,41 @@ def test_first_layer_kernels(eng, N, Cin, Cout, H, W):
         _lib.check(lib.mseg_first_wgrad(x4.data_ptr(), gyd.data_ptr(), N, H, W, Cout, dW.data_ptr(), ws.data_ptr(), st),
                    "first_wgrad")
         assert rel_err(dW.cpu(), w.grad) < TOL
+
+
+def test_halo_kernels_beyond_2gib(eng):
+    """Operands larger than 2 GiB (33 images of 512 x 512 x 64 fp32 = 2.2 GB): the halo kernels address one image at a
+    time, so the batch may be arbitrarily large.  Checked against the same kernels run on the two halves of the batch
+    (bit-identical forward; weight gradient = sum of the halves' gradients)."""
+    N, Cc, Co, H, W = 33, 64, 64, 512, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((N, H, W, Cc), generator=g, device="cuda")
+    assert x.numel() * 4 > 2 ** 31
+    w = (torch.randn((Co, Cc, 3, 3), generator=g, device="cuda") * 0.05)
+    b = torch.randn(Co, generator=g, device="cuda")
+    wp = eng.pack_weight(w, 9, Co, Cc, 1, Cc * 9, 9)
+
+    def fwd(xs):
+        n = xs.shape[0]
+        out = torch.empty((n, H, W, Co), device="cuda")
+        eng.igemm([eng.plain_src(xs, Cc)], wp, b, n, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Co, out, Co)
+        return out
+    full = fwd(x)
+    h0 = 16
+    assert torch.equal(full[:h0], fwd(x[:h0].contiguous())) and torch.equal(full[h0:], fwd(x[h0:].contiguous()))
+    # spot check of one far image against torch on the CPU
+    ref = F.conv2d(nchw(x[N - 1:].cpu()), w.cpu(), b.cpu(), padding=1)
+    assert rel_err(nchw(full[N - 1:].cpu()), ref) < TOL
+    # weight gradient with dz := the forward output (any tensor of that shape does)
+    ws = eng.Workspace(torch.device("cuda"))
+
+    def wg(dz, xs):
+        n = xs.shape[0]
+        dW = torch.empty_like(w)
+        eng.wgrad(eng.plain_src(dz, Co), [eng.plain_src(xs, Cc)], dW, n, H, W, H, W, 3, 3, 1, 1, ws)
+        return dW
+    dW = wg(full, x)
+    parts = wg(full[:h0].contiguous(), x[:h0].contiguous()) + wg(full[h0:].contiguous(), x[h0:].contiguous())
+    assert rel_err(dW.cpu(), parts.cpu()) < TOL
+    del full, x
+    torch.cuda.empty_cache()
