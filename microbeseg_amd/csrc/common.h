@@ -89,9 +89,13 @@ __device__ __forceinline__ unsigned xcd_logical_id(unsigned hw_id, unsigned nwg)
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (hw_id >> 3);
 }
 
-// max(v, lo) as ONE VALU instruction (v_med3_f32); fmaxf lowers to canonicalize + v_max.  lo = 0 -> ReLU, -FLT_MAX -> no-op
+// max(v, lo) as ONE VALU instruction.  fmaxf / fmed3f lower to a canonicalising v_max(v, v) followed by the v_max proper;
+// the instruction itself already returns the non-NaN operand, so it is emitted directly.  lo = 0 -> ReLU,
+// -FLT_MAX -> no-op.
 __device__ __forceinline__ float clamp_lo(float v, float lo) {
-  return __builtin_amdgcn_fmed3f(v, lo, __builtin_inff());
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+  return r;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

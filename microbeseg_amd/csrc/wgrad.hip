@@ -14,6 +14,9 @@
 
 #define WG_PIX 32
 #define WG_LDS 68
+// halo kernel: rows of exactly 256 bytes, so that two slab rows are one ds_read2st64_b32 with immediate offsets (no
+// per-row address arithmetic in the K-loop); b32 reads of 32 consecutive floats per half-wave stay conflict-free
+#define WH_LDS 64
 
 // identity affine for operands without tables (filled once per device by the launcher)
 __device__ float g_wg_ident_scale[4];
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   constexpr int tw_log2 = TWL;
   constexpr int PTR = 0;
   constexpr int QROWS_MAX = 48;                       // TW = 4: 8 x 6
-  constexpr int STAGE = (WG_PIX + QROWS_MAX) * WG_LDS;
+  constexpr int STAGE = (WG_PIX + QROWS_MAX) * WH_LDS;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   }
   // LDS float offset of the B fragment of pixel k = 2 kk + lh: slab row (k / TW) * QW + k % TW.  TW >= 2, so k and k - lh
   // lie in the same block row: offset = compile-time part (kk) + lane part (lh, wn, li)
-  const int blane = lh * WG_LDS + wn * 32 + li;
+  const int blane = lh * WH_LDS + wn * 32 + li;
 
   float4 rp[2], rq[3];
   float pm[2], qm[3];
@@ -574,13 +577,13 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   auto commit = [&](float* stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(stage + (spx + 16 * i) * WG_LDS + sc4 * 4) =
+      *reinterpret_cast<float4*>(stage + (spx + 16 * i) * WH_LDS + sc4 * 4) =
           xf(rp[i], psc, psh, PTR ? pm[i] : 1.f, p.P.act, plo, PTR);
-    float* qst = stage + WG_PIX * WG_LDS;
+    float* qst = stage + WG_PIX * WH_LDS;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < 2 || qlive[i])
-        *reinterpret_cast<float4*>(qst + (spx + 16 * i) * WG_LDS + sc4 * 4) =
+        *reinterpret_cast<float4*>(qst + (spx + 16 * i) * WH_LDS + sc4 * 4) =
             xf(rq[i], qsc, qsh, QTR ? qm[i] : 1.f, qs.act, qlo, QTR);
   };
 
@@ -593,16 +596,16 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   for (int step = 0; step < nsteps; ++step) {
     issue(step + 1);
     const float* st = lds + buf * STAGE;
-    const float* qst = st + WG_PIX * WG_LDS + blane;
+    const float* qst = st + WG_PIX * WH_LDS + blane;
     float a[16];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WG_LDS + wm * 32 + li];
+    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WH_LDS + wm * 32 + li];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         constexpr int dummy = 0; (void)dummy;
-        const float b = qst[((((2 * kk) >> tw_log2) * QW + ((2 * kk) & (TW - 1))) + kx) * WG_LDS];   // column + kx of the slab
+        const float b = qst[((((2 * kk) >> tw_log2) * QW + ((2 * kk) & (TW - 1))) + kx) * WH_LDS];   // column + kx of the slab
         acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
       }
     }
