@@ -214,6 +214,31 @@ int mseg_distance_postprocess_sweep(const float* border, const float* cell, int 
                                     int32_t* n_instances_dev, int32_t* status_dev, void* ws, size_t ws_bytes,
                                     void* stream);
 
+/* ---- training augmentation on the device (src/training/mytransforms.py:12-406) ------------------
+ * The reference pipeline Flip -> Contrast -> Scaling -> Rotate -> Blur -> Noise -> ToTensor runs per sample on the CPU; here
+ * the host draws every sample's random decisions along the same decision tree and these calls apply them to a batch of
+ * fp32 planes [N][H][W] (uint16 value range until the final normalisation).  All *_dev arguments are device arrays.
+ *   flip: codes[N] in 0..7 = identity, fliplr, flipud, rot90, rot180, rot270, fliplr+rot90, flipud+rot90 (np.rot90: ccw).
+ *   affine: mats[N][6], source (x, y) = (m0 x + m1 y + m2, m3 x + m4 y + m5) of destination pixel (x, y); bilinear
+ *           (nearest != 0: order 0 for uint8 labels), constant border 0; apply[N] == 0 copies the sample.
+ *   blur: scipy.ndimage.gaussian_filter semantics (radius int(4 sigma + 0.5), 'reflect'); sigma <= 0 copies.
+ *   stats: {min, max, mean}[N] (+ 65536-bin histogram per sample when hist != NULL).
+ *   contrast_params / contrast: choice[N][4] = {mode, a, b, -}: mode 1 stretch to the (a, b) percentiles
+ *           (np.percentile + rescale_intensity), mode 2 contrast factor a and gamma b (mytransforms.py:103-122).
+ *   noise_normalize: additive Gaussian noise of sigma = frac[N] * max (0: none), clip to uint16, then ToTensor's
+ *           min_max_normalization to [-1, 1] with (vmin, vmax).                                                     */
+int mseg_aug_u16_to_f32(const uint16_t* in, float* out, size_t n, void* stream);
+int mseg_aug_flip(const float* in, float* out, int N, int H, int W, const int32_t* codes_dev, void* stream);
+int mseg_aug_affine(const float* in, float* out, int N, int H, int W, const float* mats_dev, const int32_t* apply_dev,
+                    int nearest, void* stream);
+int mseg_aug_blur(const float* in, float* tmp, float* out, int N, int H, int W, const float* sigmas_dev, void* stream);
+int mseg_aug_stats(const float* in, int N, int H, int W, float* stats_dev, uint32_t* hist_dev, void* stream);
+int mseg_aug_contrast_params(const float* stats_dev, const uint32_t* hist_dev, const float* choice_dev, int N, int HW,
+                             float* par_dev, void* stream);
+int mseg_aug_contrast(const float* in, float* out, int N, int H, int W, const float* par_dev, void* stream);
+int mseg_aug_noise_normalize(const float* in, float* out, int N, int H, int W, const float* frac_dev,
+                             const float* stats_dev, uint32_t seed, float vmin, float vmax, void* stream);
+
 /* ---- evaluation helpers (EvalWorker.calc_scores, src/evaluation/eval.py:248-256) -----------------
  * mseg_eval_relabel: border_correction(mask, border_width) (src/utils/utils.py:25-47: instances not visible inside the
  *   frame minus its border are deleted) followed by skimage.measure.label (8-neighbours of EQUAL value connect; new ids

@@ -82,6 +82,14 @@ SIGNATURES = {
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_distance_postprocess_sweep": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P, _P,
                                              _P, _P, _SZ, _P]),
+    "mseg_aug_u16_to_f32": (_I, [_P, _P, _SZ, _P]),
+    "mseg_aug_flip": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "mseg_aug_affine": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "mseg_aug_blur": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "mseg_aug_stats": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "mseg_aug_contrast_params": (_I, [_P, _P, _P, _I, _I, _P, _P]),
+    "mseg_aug_contrast": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "mseg_aug_noise_normalize": (_I, [_P, _P, _I, _I, _I, _P, _P, C.c_uint32, _F, _F, _P]),
     "mseg_eval_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_eval_relabel": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mseg_eval_pair_counts": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -92,7 +92,8 @@ class TrainWorker(QObject):
                                           filters=train_configs['architecture'][4])
 
                     net = make_net()
-                    data_transforms = augmentors(label_type=label_type, min_value=0, max_value=65535)
+                    data_transforms = augmentors(label_type=label_type, min_value=0, max_value=65535,
+                                                 device_augmentation=getattr(self, 'augment', True))
                     train_configs['data_transforms'] = str(data_transforms)
                     datasets = {x: TrainingDataset(root_dir=path_data, label_type=label_type, mode=x,
                                                    transform=data_transforms[x]) for x in ['train', 'val']}
@@ -164,6 +165,15 @@ class TrainWorker(QObject):
         world, rank = parallel.world_size(), parallel.rank()
         rank0 = rank == 0
         print_output = print_output and rank0
+        # 'train' transform of the reference = augmentation + ToTensor (mytransforms.py:24-31); here the DataLoader delivers
+        # raw crops and the augmentation runs on the device, batch-wise (training/device_augment.py)
+        device_augment = None
+        train_tf = getattr(datasets['train'], 'transform', None)
+        if getattr(train_tf, 'device_augment', False):
+            if device.type != 'cuda':
+                raise RuntimeError("device augmentation needs the MI355X HIP path (no CPU fallback)")
+            from .device_augment import DeviceAugment
+            device_augment = DeviceAugment(configs['label_type'], train_tf.min_value, train_tf.max_value)
 
         if best_loss < 1e3:  # second Ranger run
             second_run = True
@@ -256,16 +266,25 @@ class TrainWorker(QObject):
                 running_loss = 0.0
                 seen = 0
 
+                dev_aug = device_augment if phase == 'train' else None
                 for samples in dataloader[phase]:
                     if configs['label_type'] == 'distance':
                         img_batch, border_label_batch, cell_label_batch = samples
                         img_batch = img_batch.to(device, non_blocking=True)
                         cell_label_batch = cell_label_batch.to(device, non_blocking=True)
                         border_label_batch = border_label_batch.to(device, non_blocking=True)
+                        if dev_aug is not None:      # Flip .. Noise + ToTensor of the reference's 'train' transform, on the device
+                            img_batch, (border_label_batch, cell_label_batch) = dev_aug(
+                                img_batch[:, 0], [(border_label_batch[:, 0], 'linear'), (cell_label_batch[:, 0], 'linear')])
+                            border_label_batch = border_label_batch.unsqueeze(1)
+                            cell_label_batch = cell_label_batch.unsqueeze(1)
                     else:
                         img_batch, label_batch = samples
                         img_batch = img_batch.to(device, non_blocking=True)
                         label_batch = label_batch.to(device, non_blocking=True)
+                        if dev_aug is not None:
+                            img_batch, (label_batch,) = dev_aug(img_batch[:, 0], [(label_batch, 'nearest')])
+                            label_batch = label_batch.to(torch.long)
 
                     optimizer.zero_grad()
                     with torch.set_grad_enabled(phase == 'train'):

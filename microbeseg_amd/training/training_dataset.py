@@ -7,7 +7,9 @@ method (label int64 (H, W) in {0, 1, 2}).  On-disk layout
 ``cell_dist_<id>.tif`` + ``neighbor_dist_<id>.tif`` (distance) or ``boundary_<id>.tif`` (boundary).
 
 The reference's CPU augmentation pipeline (flip / rotate / scale / blur / noise / contrast, mytransforms.py:12-362)
-is outside the hot path; ``augmentors`` here returns the ToTensor stage only.
+runs on the device here (``training/device_augment.py``): for the 'train' phase ``augmentors`` returns
+``RawToTensor`` — the un-normalised crop and its labels — and ``TrainWorker`` hands the batch to ``DeviceAugment``, whose
+last stage is ToTensor's normalisation.  The 'val' phase is plain ``ToTensor`` as in the reference.
 """
 import numpy as np
 import torch
@@ -44,10 +46,43 @@ class ToTensor(object):
         return f"ToTensor(label_type={self.label_type!r}, min_value={self.min_value}, max_value={self.max_value})"
 
 
-def augmentors(label_type, min_value, max_value):
-    """ Transforms per phase (reference mytransforms.py:12-35 returns augmentation + ToTensor for 'train'). """
+class RawToTensor(object):
+    """ 'train' phase: the raw crop for the device augmentation — image as int32 (uint16 values, no normalisation),
+    labels as in ToTensor.  ``min_value`` / ``max_value`` travel along for DeviceAugment's final normalisation. """
+    device_augment = True
+
+    def __init__(self, label_type, min_value, max_value):
+        self.min_value = min_value
+        self.max_value = max_value
+        self.label_type = label_type
+
+    def __call__(self, sample):
+        for key in sample:
+            if key != 'id':
+                sample[key] = np.transpose(sample[key], (2, 0, 1))     # (H, W, C) -> (C, H, W)
+        img = torch.from_numpy(np.ascontiguousarray(sample['image']).astype(np.int32))
+        if self.label_type == 'boundary':
+            label = torch.from_numpy(np.ascontiguousarray(sample['label']))[0, :, :].to(torch.long)
+            return img, label
+        elif self.label_type == 'distance':
+            cell_label = torch.from_numpy(np.ascontiguousarray(sample['cell_label'])).to(torch.float)
+            border_label = torch.from_numpy(np.ascontiguousarray(sample['border_label'])).to(torch.float)
+            return img, border_label, cell_label
+        raise Exception('Unknown label type')
+
+    def __repr__(self):
+        return ("Compose(Flip(p=1.0), Contrast(p=0.45), Scaling(p=0.25), Rotate(p=0.25), Blur(p=0.3), Noise(p=0.3), "
+                f"ToTensor(label_type={self.label_type!r}, min_value={self.min_value}, max_value={self.max_value})) "
+                "[on device]")
+
+
+def augmentors(label_type, min_value, max_value, device_augmentation=True):
+    """ Transforms per phase (reference mytransforms.py:12-35: augmentation + ToTensor for 'train', ToTensor for 'val').
+    ``device_augmentation=False`` gives the un-augmented ToTensor for both phases (parity tests, benchmarks). """
     t = ToTensor(label_type=label_type, min_value=min_value, max_value=max_value)
-    return {'train': t, 'val': t}
+    if not device_augmentation:
+        return {'train': t, 'val': t}
+    return {'train': RawToTensor(label_type=label_type, min_value=min_value, max_value=max_value), 'val': t}
 
 
 class TrainingDataset(Dataset):

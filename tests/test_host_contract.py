@@ -97,3 +97,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.mseg_strerror(-1).decode().startswith("invalid")
     assert lib.mseg_norm_workspace_bytes(2, 1024, 64) > 0 and lib.mseg_postproc_workspace_bytes(64, 64) > 0
     assert lib.mseg_igemm(None, None) == -1          # argument validation happens before any GPU work
+
+
+def test_augmentation_decision_tree_frequencies():
+    """draw_parameters follows the reference's probabilities (mytransforms.py:24-29): Flip 1.0 over 8 symmetries,
+    Contrast 0.45, Scaling 0.25, Rotate 0.25, Blur 0.3, Noise 0.3, and the parameter ranges."""
+    import random
+    from microbeseg_amd.training.device_augment import draw_parameters, scale_matrices, rotation_matrices
+    p = draw_parameters(20000, random.Random(3), np.random.default_rng(3))
+    assert set(np.unique(p["flip"])) == set(range(8))
+    for key, want in (("scale_apply", 0.25), ("rot_apply", 0.25)):
+        assert abs(p[key].mean() - want) < 0.015
+    assert abs((p["contrast"][:, 0] > 0).mean() - 0.45) < 0.015
+    assert abs((p["contrast"][:, 0] == 2).mean() - 0.15) < 0.01
+    assert abs((p["blur_sigma"] > 0).mean() - 0.3) < 0.015 and abs((p["noise_frac"] > 0).mean() - 0.3) < 0.015
+    b = p["blur_sigma"][p["blur_sigma"] > 0]
+    assert b.min() >= 1.0 and b.max() < 2.0
+    assert set(np.round(p["noise_frac"][p["noise_frac"] > 0] * 100).astype(int)) == {1, 2, 3, 4, 5}
+    s = p["scale_xy"][p["scale_apply"] > 0]
+    assert s.min() >= 0.85 and s.max() <= 1.15 and abs(p["rot_deg"]).max() <= 45
+    g = p["contrast"][p["contrast"][:, 0] == 2]
+    assert g[:, 1].min() >= 0.75 and g[:, 1].max() <= 1.25 and g[:, 2].min() >= 0.7 and g[:, 2].max() <= 1.3
+    # the centre is a fixed point of both warps
+    m = np.concatenate([scale_matrices(np.array([[1.1, 0.9]]), 31, 41), rotation_matrices(np.array([33.0]), 31, 41)])
+    for q in m:
+        assert abs(q[0] * 20 + q[1] * 15 + q[2] - 20) < 1e-4 and abs(q[3] * 20 + q[4] * 15 + q[5] - 15) < 1e-4

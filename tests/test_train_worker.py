@@ -72,6 +72,7 @@ def test_train_worker_host_logic_cpu(tmp_path, monkeypatch, label_type):
     monkeypatch.setattr(T, "build_unet", fake_build)
     monkeypatch.setattr(T, "get_loss", fake_loss)
     w = T.TrainWorker()
+    w.augment = False      # the device augmentation needs the GPU; this test exercises the host logic only
     msgs, prog = [], []
     w.text_output.connect(msgs.append)
     w.progress.connect(prog.append)
