@@ -143,3 +143,26 @@ def test_pipeline_shapes_ranges_and_label_consistency(aug):
     assert float(out.min()) >= -1.0 and float(out.max()) <= 1.0
     assert torch.equal(c2, b2)                                               # same geometry for both label planes
     assert float(c2.min()) >= 0.0 and float(c2.max()) <= 1.0 + 1e-6
+
+
+def test_pipeline_matches_cpu_restatement_with_identical_parameters(aug):
+    """Whole pipeline (no noise: its generator differs) vs oracle/augment_ref.py driven by the same drawn parameters."""
+    import pathlib
+    import random
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+    from oracle import augment_ref
+    rng = np.random.default_rng(6)
+    n, s = 24, 64
+    img = (ndi.gaussian_filter(rng.random((n, s, s)), 2.0) * 1.2e5).clip(0, 65535).astype(np.uint16)
+    cell = ndi.gaussian_filter(rng.random((n, s, s)), 1.5).astype(np.float32)
+    cls = np.kron(rng.integers(0, 3, (n, s // 8, s // 8)), np.ones((8, 8))).astype(np.float32)
+    p = aug.draw_parameters(n, random.Random(5), np.random.default_rng(5))
+    p["noise_frac"][:] = 0
+    assert p["scale_apply"].any() and p["rot_apply"].any() and (p["blur_sigma"] > 0).any() and (p["contrast"][:, 0] == 2).any()
+    out, (oc, ol) = _run(aug, img, [(cell, "linear"), (cls, "nearest")], p)
+    for i in range(n):
+        want, (wc, wl) = augment_ref.augment_sample(img[i], [(cell[i], "linear"), (cls[i], "nearest")], p, i)
+        assert np.abs(out[i] - want).max() < 5e-4, i
+        assert np.abs(oc[i] - wc).max() < 1e-4, i
+        assert (ol[i][4:-4, 4:-4] != wl[4:-4, 4:-4]).mean() < 0.03, i
