@@ -225,6 +225,8 @@ int mseg_distance_postprocess_sweep(const float* border, const float* cell, int 
  *   stats: {min, max, mean}[N] (+ 65536-bin histogram per sample when hist != NULL).
  *   contrast_params / contrast: choice[N][4] = {mode, a, b, -}: mode 1 stretch to the (a, b) percentiles
  *           (np.percentile + rescale_intensity), mode 2 contrast factor a and gamma b (mytransforms.py:103-122).
+ *   clahe: choice[s][0] == 3: contrast-limited adaptive histogram equalisation (equalize_adapthist defaults: 8 x 8 tiles,
+ *           256 bins, clip limit 0.01; mytransforms.py:92-95), other samples copied; ws >= mseg_aug_clahe_workspace_bytes(N).
  *   noise_normalize: additive Gaussian noise of sigma = frac[N] * max (0: none), clip to uint16, then ToTensor's
  *           min_max_normalization to [-1, 1] with (vmin, vmax).                                                     */
 int mseg_aug_u16_to_f32(const uint16_t* in, float* out, size_t n, void* stream);
@@ -236,6 +238,8 @@ int mseg_aug_stats(const float* in, int N, int H, int W, float* stats_dev, uint3
 int mseg_aug_contrast_params(const float* stats_dev, const uint32_t* hist_dev, const float* choice_dev, int N, int HW,
                              float* par_dev, void* stream);
 int mseg_aug_contrast(const float* in, float* out, int N, int H, int W, const float* par_dev, void* stream);
+size_t mseg_aug_clahe_workspace_bytes(int N);
+int mseg_aug_clahe(const float* in, float* out, int N, int H, int W, const float* choice_dev, void* ws, void* stream);
 int mseg_aug_noise_normalize(const float* in, float* out, int N, int H, int W, const float* frac_dev,
                              const float* stats_dev, uint32_t seed, float vmin, float vmax, void* stream);
 

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mseg_aug_stats": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "mseg_aug_contrast_params": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "mseg_aug_contrast": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "mseg_aug_clahe_workspace_bytes": (_SZ, [_I]),
+    "mseg_aug_clahe": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "mseg_aug_noise_normalize": (_I, [_P, _P, _I, _I, _I, _P, _P, C.c_uint32, _F, _F, _P]),
     "mseg_eval_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_eval_relabel": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),

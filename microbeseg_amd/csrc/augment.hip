@@ -299,6 +299,106 @@ extern "C" int mseg_aug_contrast(const float* in, float* out, int N, int H, int 
   return MSEG_OK;
 }
 
+// ---- Contrast, CLAHE branch (mytransforms.py:92-95: skimage.exposure.equalize_adapthist(img, clip_limit=0.01)) -----------
+// Contrast-limited adaptive histogram equalisation after Zuiderveld, with scikit-image's defaults: an 8 x 8 grid of tiles
+// (kernel_size = shape / 8), 256 bins over 2^14 grey levels, histogram clipped at max(1, 0.01 * tile pixels) with the
+// excess redistributed, cumulative mapping per tile, bilinear interpolation between the mappings of the four nearest tile
+// centres.  Output back in the uint16 range (the reference multiplies by 65535 and truncates).  Distributional stand-in
+// for the library routine (its padding / rounding details are not reproduced).  mode[s] != 3: sample untouched.
+#define CLAHE_T 8
+#define CLAHE_BINS 256
+#define CLAHE_GRAY 16384
+
+__global__ __launch_bounds__(256) void aug_clahe_maps_kernel(const float* __restrict__ in, int H, int W,
+                                                             const float* __restrict__ choice,
+                                                             float* __restrict__ maps /*[N][64][256]*/) {
+  __shared__ unsigned hist[CLAHE_BINS];
+  __shared__ float cum[CLAHE_BINS];
+  const int s = blockIdx.y, tile = blockIdx.x;
+  if ((int)choice[4 * s] != 3) return;
+  const int ty = tile / CLAHE_T, tx = tile - ty * CLAHE_T;
+  const int y0 = (int)((long long)ty * H / CLAHE_T), y1 = (int)((long long)(ty + 1) * H / CLAHE_T);
+  const int x0 = (int)((long long)tx * W / CLAHE_T), x1 = (int)((long long)(tx + 1) * W / CLAHE_T);
+  const int tw = x1 - x0, npx = (y1 - y0) * tw;
+  hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const float* p = in + (size_t)s * H * W;
+  for (int i = threadIdx.x; i < npx; i += 256) {
+    const int y = y0 + i / tw, x = x0 + i % tw;
+    int g = (int)floorf(p[(size_t)y * W + x] * ((CLAHE_GRAY - 1) / 65535.f) + 0.5f);
+    g = g < 0 ? 0 : (g > CLAHE_GRAY - 1 ? CLAHE_GRAY - 1 : g);
+    atomicAdd(&hist[g / (CLAHE_GRAY / CLAHE_BINS)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int clim = (int)(0.01f * (float)npx);
+    if (clim < 1) clim = 1;
+    int excess = 0;
+    for (int b = 0; b < CLAHE_BINS; ++b) if ((int)hist[b] > clim) excess += (int)hist[b] - clim;
+    const int incr = excess / CLAHE_BINS, upper = clim - incr;
+    for (int b = 0; b < CLAHE_BINS; ++b) {
+      const int h = (int)hist[b];
+      if (h > clim) hist[b] = (unsigned)clim;
+      else if (h > upper) { excess -= clim - h; hist[b] = (unsigned)clim; }
+      else { excess -= incr; hist[b] = (unsigned)(h + incr); }
+    }
+    for (int guard = 0; excess > 0 && guard < 64; ++guard) {            // leftover: one count per bin, cyclically
+      for (int b = 0; b < CLAHE_BINS && excess > 0; ++b)
+        if ((int)hist[b] < clim) { hist[b] += 1u; --excess; }
+    }
+    float run = 0.f;
+    const float scale = (float)(CLAHE_GRAY - 1) / (float)(npx > 0 ? npx : 1);
+    for (int b = 0; b < CLAHE_BINS; ++b) {
+      run += (float)hist[b];
+      cum[b] = fminf(run * scale, (float)(CLAHE_GRAY - 1));
+    }
+  }
+  __syncthreads();
+  maps[((size_t)s * CLAHE_T * CLAHE_T + tile) * CLAHE_BINS + threadIdx.x] = cum[threadIdx.x];
+}
+
+__global__ void aug_clahe_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W,
+                                       const float* __restrict__ choice, const float* __restrict__ maps) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int s = (int)(t / hw);
+    const float v = in[t];
+    if ((int)choice[4 * s] != 3) { out[t] = v; continue; }
+    const int r = (int)(t - (size_t)s * hw);
+    const int y = r / W, x = r - y * W;
+    int g = (int)floorf(v * ((CLAHE_GRAY - 1) / 65535.f) + 0.5f);
+    g = g < 0 ? 0 : (g > CLAHE_GRAY - 1 ? CLAHE_GRAY - 1 : g);
+    const int bin = g / (CLAHE_GRAY / CLAHE_BINS);
+    // position in units of tiles relative to the tile centres
+    const float fy = ((float)y + 0.5f) * CLAHE_T / (float)H - 0.5f, fx = ((float)x + 0.5f) * CLAHE_T / (float)W - 0.5f;
+    int ty0 = (int)floorf(fy), tx0 = (int)floorf(fx);
+    const float ay = fy - (float)ty0, ax = fx - (float)tx0;
+    const int ty1 = ty0 + 1 > CLAHE_T - 1 ? CLAHE_T - 1 : ty0 + 1, tx1 = tx0 + 1 > CLAHE_T - 1 ? CLAHE_T - 1 : tx0 + 1;
+    ty0 = ty0 < 0 ? 0 : ty0; tx0 = tx0 < 0 ? 0 : tx0;
+    const float* m = maps + (size_t)s * CLAHE_T * CLAHE_T * CLAHE_BINS + bin;
+    const float m00 = m[(ty0 * CLAHE_T + tx0) * CLAHE_BINS], m01 = m[(ty0 * CLAHE_T + tx1) * CLAHE_BINS];
+    const float m10 = m[(ty1 * CLAHE_T + tx0) * CLAHE_BINS], m11 = m[(ty1 * CLAHE_T + tx1) * CLAHE_BINS];
+    const float mapped = (1.f - ay) * ((1.f - ax) * m00 + ax * m01) + ay * ((1.f - ax) * m10 + ax * m11);
+    out[t] = floorf(fminf(fmaxf(mapped / (float)(CLAHE_GRAY - 1), 0.f), 1.f) * 65535.f);
+  }
+}
+
+extern "C" size_t mseg_aug_clahe_workspace_bytes(int N) {
+  return N > 0 ? (size_t)N * CLAHE_T * CLAHE_T * CLAHE_BINS * sizeof(float) : 0;
+}
+
+extern "C" int mseg_aug_clahe(const float* in, float* out, int N, int H, int W, const float* choice_dev, void* ws,
+                              void* stream) {
+  if (!in || !out || !choice_dev || !ws || N <= 0 || H < CLAHE_T || W < CLAHE_T || in == out) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(aug_clahe_maps_kernel, dim3(CLAHE_T * CLAHE_T, N), dim3(256), 0, st, in, H, W, choice_dev,
+                     (float*)ws);
+  hipLaunchKernelGGL(aug_clahe_apply_kernel, dim3(aug_blocks((size_t)N * H * W)), dim3(AUG_BLOCK), 0, st, in, out, N, H,
+                     W, choice_dev, (const float*)ws);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
 // ---- Noise (mytransforms.py:235-256: additive Gaussian noise, sigma = 1..5 % of the image maximum, result clipped to the
 // uint16 range) fused with ToTensor's min-max normalisation (utils.py:50-74: clip to [min, max], 2 (v - min) / (max - min) - 1).
 // Counter-based generator: two 32-bit hashes of (seed, sample, pixel) -> Box-Muller.  frac[s] = 0.01 .. 0.05 (0: no noise),

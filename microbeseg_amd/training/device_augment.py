@@ -15,9 +15,9 @@ pipeline to the whole batch in HBM (csrc/augment.hip).  What is kept from the re
     the image only; the output equals ToTensor's: image in [-1, 1] (min-max normalisation), labels unchanged in type.
 
 Differences (the reference pipeline is not numerically pinned — unseeded RNG, uint16 round trips between stages):
-intermediate images stay fp32 instead of being rounded to uint16 after every stage; the CLAHE branch of Contrast
-(skimage.exposure.equalize_adapthist, 1/3 of the contrast augmentations) is replaced by the 0.2/99.8 percentile stretch;
-imgaug's affine warps are reproduced with centre ((W-1)/2, (H-1)/2), bilinear / nearest sampling and a constant 0 border.
+intermediate images stay fp32 instead of being rounded to uint16 after every stage; the CLAHE branch of Contrast is
+Zuiderveld's algorithm with scikit-image's defaults (8 x 8 tiles, 256 bins, clip limit 0.01) without the library's
+padding / rounding details; imgaug's affine warps are reproduced with centre ((W-1)/2, (H-1)/2), bilinear / nearest sampling and a constant 0 border.
 """
 import ctypes as C
 import math
@@ -45,8 +45,8 @@ def draw_parameters(n, rng=random, nprng=np.random):
             flip[i] = rng.randint(0, 7)
         if rng.random() < 0.45:                       # Contrast(p=0.45): :84-90
             h = rng.randint(0, 2)
-            if h == 0:                                # CLAHE branch -> percentile stretch (see module docstring)
-                contrast[i] = (1, 0.2, 99.8, 0)
+            if h == 0:                                # CLAHE (equalize_adapthist, clip_limit 0.01)
+                contrast[i] = (3, 0, 0, 0)
             elif h == 1:
                 contrast[i] = (1, 0.2, 99.8, 0) if rng.randint(0, 1) == 0 else (1, 0.1, 99.9, 0)
             else:
@@ -134,6 +134,11 @@ class DeviceAugment:
                                                     par.data_ptr(), st), "aug_contrast_params")
             _lib.check(lib.mseg_aug_contrast(a.data_ptr(), b.data_ptr(), N, H, W, par.data_ptr(), st), "aug_contrast")
             a, b = b, a
+            if (params["contrast"][:, 0] == 3).any():
+                cws = torch.empty(lib.mseg_aug_clahe_workspace_bytes(N), dtype=torch.uint8, device=dev)
+                _lib.check(lib.mseg_aug_clahe(a.data_ptr(), b.data_ptr(), N, H, W, choice.data_ptr(), cws.data_ptr(), st),
+                           "aug_clahe")
+                a, b = b, a
         # Scaling, Rotate (image + labels)
         warps = []
         if params["scale_apply"].any():

@@ -37,6 +37,54 @@ def rotation_matrix(deg, H, W):
     return (c, s, cx - c * cx - s * cy, -s, c, cy + s * cx - c * cy)
 
 
+def clahe(v, tiles=8, bins=256, gray=16384, clip=0.01):
+    """Zuiderveld's CLAHE with scikit-image's defaults, the variant csrc/augment.hip implements (module docstring there)."""
+    H, W = v.shape
+    g = np.clip(np.floor(v * ((gray - 1) / 65535.0) + 0.5), 0, gray - 1).astype(np.int64)
+    b = g // (gray // bins)
+    maps = np.zeros((tiles, tiles, bins), np.float32)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            y0, y1 = ty * H // tiles, (ty + 1) * H // tiles
+            x0, x1 = tx * W // tiles, (tx + 1) * W // tiles
+            hist = np.bincount(b[y0:y1, x0:x1].ravel(), minlength=bins).astype(np.int64)
+            npx = (y1 - y0) * (x1 - x0)
+            clim = max(1, int(np.float32(clip) * np.float32(npx)))
+            excess = int(np.maximum(hist - clim, 0).sum())
+            incr, upper = excess // bins, clim - excess // bins
+            for k in range(bins):
+                h = hist[k]
+                if h > clim:
+                    hist[k] = clim
+                elif h > upper:
+                    excess -= clim - h
+                    hist[k] = clim
+                else:
+                    excess -= incr
+                    hist[k] = h + incr
+            guard = 0
+            while excess > 0 and guard < 64:
+                for k in range(bins):
+                    if excess <= 0:
+                        break
+                    if hist[k] < clim:
+                        hist[k] += 1
+                        excess -= 1
+                guard += 1
+            scale = np.float32(gray - 1) / np.float32(max(npx, 1))
+            maps[ty, tx] = np.minimum(np.cumsum(hist.astype(np.float32)) * scale, np.float32(gray - 1))
+    yy, xx = np.mgrid[0:H, 0:W]
+    fy = (yy.astype(np.float32) + 0.5) * tiles / np.float32(H) - 0.5
+    fx = (xx.astype(np.float32) + 0.5) * tiles / np.float32(W) - 0.5
+    ty0, tx0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+    ay, ax = fy - ty0, fx - tx0
+    ty1, tx1 = np.minimum(ty0 + 1, tiles - 1), np.minimum(tx0 + 1, tiles - 1)
+    ty0, tx0 = np.maximum(ty0, 0), np.maximum(tx0, 0)
+    m = (1 - ay) * ((1 - ax) * maps[ty0, tx0, b] + ax * maps[ty0, tx1, b]) + \
+        ay * ((1 - ax) * maps[ty1, tx0, b] + ax * maps[ty1, tx1, b])
+    return np.floor(np.clip(m / np.float32(gray - 1), 0, 1) * 65535.0)
+
+
 def augment_sample(img, labels, p, i, min_value=0.0, max_value=65535.0, noise_rng=None):
     """img: (H, W) uint16; labels: list of ((H, W) array, 'linear' | 'nearest'); p: dict of parameter arrays, i: sample index.
     Returns (image fp64 in [-1, 1], [labels])."""
@@ -53,6 +101,8 @@ def augment_sample(img, labels, p, i, min_value=0.0, max_value=65535.0, noise_rn
         mn, rg = u.min(), u.max() - u.min()
         u = np.power((u - mn) / float(rg + 1e-7), b) * rg + mn
         v = np.floor(np.clip(u, 0, 1) * 65535)
+    elif mode == 3:
+        v = clahe(v)
     warps = []
     if p["scale_apply"][i]:
         warps.append(scale_matrix(float(p["scale_xy"][i][0]), float(p["scale_xy"][i][1]), H, W))

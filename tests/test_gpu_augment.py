@@ -159,10 +159,12 @@ def test_pipeline_matches_cpu_restatement_with_identical_parameters(aug):
     cls = np.kron(rng.integers(0, 3, (n, s // 8, s // 8)), np.ones((8, 8))).astype(np.float32)
     p = aug.draw_parameters(n, random.Random(5), np.random.default_rng(5))
     p["noise_frac"][:] = 0
-    assert p["scale_apply"].any() and p["rot_apply"].any() and (p["blur_sigma"] > 0).any() and (p["contrast"][:, 0] == 2).any()
+    assert p["scale_apply"].any() and p["rot_apply"].any() and (p["blur_sigma"] > 0).any()
+    assert {1, 2, 3} <= set(p["contrast"][:, 0].astype(int))
     out, (oc, ol) = _run(aug, img, [(cell, "linear"), (cls, "nearest")], p)
     for i in range(n):
         want, (wc, wl) = augment_ref.augment_sample(img[i], [(cell[i], "linear"), (cls[i], "nearest")], p, i)
-        assert np.abs(out[i] - want).max() < 5e-4, i
+        tol = 3e-3 if p["contrast"][i, 0] == 3 else 5e-4      # CLAHE: a pixel on a bin edge may fall in the neighbour bin
+        assert np.abs(out[i] - want).max() < tol, i
         assert np.abs(oc[i] - wc).max() < 1e-4, i
         assert (ol[i][4:-4, 4:-4] != wl[4:-4, 4:-4]).mean() < 0.03, i

@@ -109,7 +109,7 @@ def test_augmentation_decision_tree_frequencies():
     for key, want in (("scale_apply", 0.25), ("rot_apply", 0.25)):
         assert abs(p[key].mean() - want) < 0.015
     assert abs((p["contrast"][:, 0] > 0).mean() - 0.45) < 0.015
-    assert abs((p["contrast"][:, 0] == 2).mean() - 0.15) < 0.01
+    assert abs((p["contrast"][:, 0] == 2).mean() - 0.15) < 0.01 and abs((p["contrast"][:, 0] == 3).mean() - 0.15) < 0.01
     assert abs((p["blur_sigma"] > 0).mean() - 0.3) < 0.015 and abs((p["noise_frac"] > 0).mean() - 0.3) < 0.015
     b = p["blur_sigma"][p["blur_sigma"] > 0]
     assert b.min() >= 1.0 and b.max() < 2.0
