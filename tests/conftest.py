@@ -15,3 +15,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+def pytest_collection_modifyitems(config, items):
+    # torch's DataLoader pin-memory thread repeats one DeprecationWarning per batch: keep the summary readable
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor.*:DeprecationWarning")
