@@ -81,9 +81,16 @@ typedef struct MsegIgemm {
   int32_t NB, Hi, Wi, Ho, Wo;
   int32_t KH, KW, stride, pad, mode, morder;
   int32_t Ngemm, epi, split, ld0, ld1, acc0, acc1, Cq;
+  int32_t reserved;
+  /* optional split-K scratch (small batches: fewer 3x3 stride-1 tiles than workgroup slots).  ws == NULL or too small: the
+   * launch simply is not split.  Size: mseg_igemm_workspace_bytes(). */
+  void* ws;
+  size_t ws_bytes;
 } MsegIgemm;
 
 int mseg_igemm(const MsegIgemm* p, void* stream);
+/* bytes of split-K scratch this launch would use (0: it would not be split) */
+size_t mseg_igemm_workspace_bytes(const MsegIgemm* p);
 
 /* weight gradient: G[t][mch][nch] = sum_p P[p][mch] * Q[gather(p, t)][nch], written to dst[(mch*Nch + nch)*T + t]
  * which *is* torch's layout for both Conv2d.weight (Cout,Cin,KH,KW) [P = dz, Q = conv input] and

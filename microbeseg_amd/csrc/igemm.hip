@@ -706,8 +706,13 @@ struct HaloCfg {
   static constexpr int BROWS = BN / 64;
 };
 
+// Split-K (small batches / deep levels: fewer than one tile per workgroup slot): ksplit workgroups share a tile, each
+// reducing a contiguous range of the 32-channel chunks into its own slice of a workspace [ksplit][M][Ngemm] (the host
+// passes a descriptor whose destination is that workspace); igemm_splitk_reduce_kernel sums the slices in fixed order and
+// applies bias / accumulate / the split destinations.  ksplit == 1: the plain kernel.
 template <int BN, int TR>
-__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, int tw_log2) {
+__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                            int chunks_per_split) {
   constexpr int BM = 128;
   // 8 waves (two per SIMD, same workgroup): 2 x 4 wave grid for BN = 128 (64 x 32 per wave), 4 x 2 for BN = 64 (32 x 32)
   using Cfg = HaloCfg<BN>;
@@ -729,7 +734,10 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   const int M = p.NB * H * W;
   const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
   const int ntiles_n = (p.Ngemm + BN - 1) / BN;
-  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int lid_all = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int ntiles_all = (int)gridDim.x / ksplit;
+  const int kz = lid_all / ntiles_all;                 // split index (slowest: the N tiles of an M tile stay neighbours)
+  const int lid = lid_all - kz * ntiles_all;
   const int tile_m = lid / ntiles_n, tile_n = lid - tile_m * ntiles_n;
   const int img = tile_m / (tiles_x * tiles_y);
   const int trem = tile_m - img * (tiles_x * tiles_y);
@@ -849,16 +857,18 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
       *reinterpret_cast<float4*>(Bs + (srow + 64 * i) * LDS_STRIDE + scol * 4) = rb[i];
   };
 
-  issue_halo(0);
-  issue_b(0, 0);
+  const int c_begin = kz * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  issue_halo(c_begin);
+  issue_b(c_begin, 0);
   commit_halo(Abuf);
   commit_b(Bbuf);
   __syncthreads();
 
   int bsel = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const float* As = Abuf;
-    const bool more_chunks = chunk + 1 < nchunks;
+    const bool more_chunks = chunk + 1 < c_end;
     for (int t = 0; t < 9; ++t) {
       if (t == 0 && more_chunks) issue_halo(chunk + 1);          // a whole chunk of MFMAs hides this fetch
       // weights of the next K-step (the very last step re-reads its own: keeps the body branch-free)
@@ -896,7 +906,34 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
       bsel ^= 1;
     }
   }
-  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M, tw_log2, img, oy0, ox0);
+  // split slices are addressed as further images of the workspace tensor [ksplit * NB][H][W][Ngemm]
+  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
+}
+
+// out[m][n] = bias[n] + sum_k ws[k][m][n]  (fixed order), routed like the PLAIN epilogue: columns < split to dst0, the
+// rest to dst1, each with its own leading dimension and accumulate flag.  One thread per 4 columns.
+__global__ void igemm_splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, size_t M, int N,
+                                           const float* __restrict__ bias, float* __restrict__ dst0, int ld0, int acc0,
+                                           float* __restrict__ dst1, int ld1, int acc1, int split) {
+  const int N4 = N >> 2;
+  const size_t total = M * (size_t)N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    float4 s = *reinterpret_cast<const float4*>(ws + m * N + n);
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + ((size_t)k * M + m) * N + n);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
+    const bool second = n >= split;                    // split % 4 == 0 (channel counts are multiples of 4)
+    float* d = second ? dst1 + m * ld1 + (n - split) : dst0 + m * ld0 + n;
+    if (second ? acc1 : acc0) {
+      const float4 o = *reinterpret_cast<const float4*>(d);
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(d) = s;
+  }
 }
 
 static int check_src(const MsegSrc& s) {
@@ -904,6 +941,47 @@ static int check_src(const MsegSrc& s) {
   if ((s.scale == nullptr) != (s.shift == nullptr)) return MSEG_EINVAL;
   if (s.scale && (s.ss & 3)) return MSEG_EINVAL;
   return MSEG_OK;
+}
+
+// split-K of a halo launch: only when the tiles leave most workgroup slots (2 per CU) empty and every split keeps at
+// least two 32-channel chunks; 1 = no split
+static int halo_ksplit(long long htiles, int nchunks, int* chunks_per_split) {
+  int ks = 1;
+  if (htiles < 256 && nchunks >= 4) {
+    long long want = (512 + htiles - 1) / htiles;
+    ks = (int)(want < 16 ? want : 16);
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    if (ks < 1) ks = 1;
+  }
+  *chunks_per_split = (nchunks + ks - 1) / ks;
+  return (nchunks + *chunks_per_split - 1) / *chunks_per_split;     // splits that actually get chunks
+}
+
+static bool halo_geometry(const MsegIgemm& p, int BNv, int* tw_log2_out, long long* htiles_out) {
+  if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
+        p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0))
+    return false;
+  int tw_log2 = 6;
+  while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 64 dividing W
+  const int TH = 128 >> tw_log2;
+  const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
+  *htiles_out = mt * ((p.Ngemm + BNv - 1) / BNv);
+  *tw_log2_out = tw_log2;
+  // rows of the 128-pixel tile that fall below the image are wasted matrix work (e.g. 20 x 20 images: 4 x 32 tiles
+  // cover 32 rows for 20); below 80 % the linear-M gather kernel, which wastes nothing, is the faster choice
+  return (long long)p.Hi * 5 >= (long long)((p.Hi + TH - 1) / TH) * TH * 4;
+}
+
+extern "C" size_t mseg_igemm_workspace_bytes(const MsegIgemm* pp) {
+  if (!pp) return 0;
+  const MsegIgemm& p = *pp;
+  if (p.Ngemm <= 0 || p.Cin <= 0 || p.NB <= 0 || p.Hi <= 0 || p.Wi <= 0) return 0;
+  int tw_log2 = 0, cps = 0;
+  long long htiles = 0;
+  if (!halo_geometry(p, p.Ngemm > 64 ? 128 : 64, &tw_log2, &htiles)) return 0;
+  const int ks = halo_ksplit(htiles, (p.Cin + KC - 1) / KC, &cps);
+  if (ks <= 1 || (p.Ngemm & 3)) return 0;
+  return (size_t)ks * p.NB * p.Hi * p.Wi * p.Ngemm * sizeof(float);
 }
 
 extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
@@ -969,26 +1047,39 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   fast = fast && common;
   // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient).  Its descriptors are
   // per image, so only ONE IMAGE of each operand has to stay below 2 GiB: any batch size keeps the fast path.
-  if (common && image_fits && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
-      p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0) {
-    int tw_log2 = 6;
-    while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 64 dividing W
-    const int TH = 128 >> tw_log2;
-    const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
-    const long long htiles = mt * ((p.Ngemm + BNv - 1) / BNv);
-    // rows of the 128-pixel tile that fall below the image are wasted matrix work (e.g. 20 x 20 images: 4 x 32 tiles
-    // cover 32 rows for 20); below 80 % the linear-M gather kernel, which wastes nothing, is the faster choice
-    const bool efficient = (long long)p.Hi * 5 >= (long long)((p.Hi + TH - 1) / TH) * TH * 4;
-    if (htiles <= 0x7fffffffLL && efficient) {
-      const int tr = plain ? 0 : (generic ? 2 : 1);
-      const dim3 hgrid((unsigned)htiles);
-#define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, p, tw_log2)
-      if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
-      else      { if (tr == 0) MSEG_HALO(64, 0); else if (tr == 1) MSEG_HALO(64, 1); else MSEG_HALO(64, 2); }
-#undef MSEG_HALO
-      MSEG_LAUNCH_CHECK();
-      return MSEG_OK;
+  int tw_log2 = 6;
+  long long htiles = 0;
+  if (common && image_fits && halo_geometry(p, BNv, &tw_log2, &htiles) && htiles <= 0x7fffffffLL) {
+    const int tr = plain ? 0 : (generic ? 2 : 1);
+    // split-K over the input-channel chunks when the tiles would leave most of the chip idle (small batches, deep levels)
+    int cps = 0;
+    int ks = halo_ksplit(htiles, (p.Cin + KC - 1) / KC, &cps);
+    const size_t need = (size_t)ks * (size_t)M * (size_t)p.Ngemm * sizeof(float);
+    if (ks > 1 && (!p.ws || p.ws_bytes < need || (p.Ngemm & 3) || (p.split & 3) || htiles * ks > 0x7fffffffLL)) {
+      ks = 1;
+      cps = (p.Cin + KC - 1) / KC;
     }
+    MsegIgemm q = p;                                   // descriptor of the partial launch: plain stores into the scratch
+    if (ks > 1) {
+      q.dst0 = (float*)p.ws; q.dst1 = nullptr; q.ld0 = p.Ngemm; q.ld1 = 0; q.split = p.Ngemm; q.acc0 = 0; q.acc1 = 0;
+      q.bias = nullptr;
+    }
+    const dim3 hgrid((unsigned)(htiles * ks));
+#define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
+    if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
+    else      { if (tr == 0) MSEG_HALO(64, 0); else if (tr == 1) MSEG_HALO(64, 1); else MSEG_HALO(64, 2); }
+#undef MSEG_HALO
+    MSEG_LAUNCH_CHECK();
+    if (ks > 1) {
+      const size_t total = (size_t)M * (size_t)(p.Ngemm >> 2);
+      size_t blocks = (total + 255) / 256;
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p.ws, ks,
+                         (size_t)M, p.Ngemm, p.bias, p.dst0, p.ld0, p.acc0, p.dst1, p.ld1, p.acc1,
+                         p.split < p.Ngemm ? p.split : p.Ngemm);
+      MSEG_LAUNCH_CHECK();
+    }
+    return MSEG_OK;
   }
   if (fast) {
     const int tr = plain ? 0 : (generic ? 2 : 1);

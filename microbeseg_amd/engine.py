@@ -190,6 +190,9 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+_splitk_ws = {}      # device -> grow-only scratch of the split-K igemm launches (stream-ordered reuse)
+
+
 class PackedW:
     """GEMM operand [T][Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero filled) produced by pack_weight."""
     __slots__ = ("t", "Npad", "Kpad")
@@ -234,6 +237,13 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     p.Ngemm, p.epi = Ngemm, epi
     p.split = Ngemm if split is None else split
     p.ld0, p.ld1, p.acc0, p.acc1, p.Cq = ld0, ld1, acc0, acc1, Cq
+    need = lib.mseg_igemm_workspace_bytes(C.byref(p))      # split-K scratch (small batches / deep levels only)
+    if need:
+        buf = _splitk_ws.get(dst0.device)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(need, dtype=torch.uint8, device=dst0.device)
+            _splitk_ws[dst0.device] = buf
+        p.ws, p.ws_bytes = buf.data_ptr(), buf.numel()
     if _timer is None:
         check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
         return

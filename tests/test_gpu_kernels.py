@@ -344,3 +344,48 @@ def test_halo_kernels_beyond_2gib(eng):
     assert rel_err(dW.cpu(), parts.cpu()) < TOL
     del full, x
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,two_src", [(1, 256, 256, 16, 16, False), (2, 512, 128, 8, 16, False),
+                                                    (1, 128, 64, 16, 32, True), (3, 1024, 1024, 16, 8, False)])
+def test_split_k_halo_launches(eng, N, Cin, Cout, H, W, two_src):
+    """Few tiles + many input channels: the 3x3 stride-1 launch is split over the channel chunks and reduced in a second
+    kernel (bias, accumulate flag and split destinations applied there).  Forward with norm-on-load operands and data
+    gradient with accumulate + two destinations, against torch on the CPU."""
+    from microbeseg_amd import _lib
+    g = torch.Generator().manual_seed(100 + Cin + H)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1.0, rnd(g, Cin) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_transform_cpu(z, "relu", scale, shift, False), w, b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    if two_src:
+        c0 = Cin // 2
+        n0 = _mk_node(eng, z[:, :c0], "relu", scale[:c0], shift[:c0])
+        n1 = _mk_node(eng, z[:, c0:], "relu", scale[c0:], shift[c0:])
+        srcs = [n0.src(), n1.src()]
+    else:
+        node = _mk_node(eng, z, "relu", scale, shift)
+        srcs = [node.src()]
+    # the launch must actually be a split one
+    p = _lib.MsegIgemm()
+    p.Ngemm, p.Cin, p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad = Cout, Cin, N, H, W, H, W, 3, 3, 1, 1
+    assert _lib.load().mseg_igemm_workspace_bytes(C.byref(p)) > 0
+    eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout)
+    assert rel_err(nchw(out.cpu()), ref) < TOL
+    # data gradient: accumulate into destination 0, plain store into destination 1
+    x = rnd(g, N, Cin, H, W).requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=1)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    refn = nhwc(x.grad)
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    base = rnd(g, N, H, W, Cin)
+    c0 = Cin // 2
+    d0, d1 = base[..., :c0].contiguous().cuda(), torch.full((N, H, W, Cin - c0), float("nan"), device="cuda")
+    dz = nhwc(gy).cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, c0, acc0=1,
+              dst1=d1, ld1=Cin - c0, acc1=0, split=c0)
+    assert rel_err(d0.cpu(), refn[..., :c0] + base[..., :c0]) < TOL
+    assert rel_err(d1.cpu(), refn[..., c0:]) < TOL
