@@ -604,7 +604,6 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
     for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        constexpr int dummy = 0; (void)dummy;
         const float b = qst[((((2 * kk) >> tw_log2) * QW + ((2 * kk) & (TW - 1))) + kx) * WH_LDS];   // column + kx of the slab
         acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[kx], 0, 0, 0);
       }
