@@ -250,6 +250,11 @@ int mseg_aug_clahe(const float* in, float* out, int N, int H, int W, const float
 int mseg_aug_noise_normalize(const float* in, float* out, int N, int H, int W, const float* frac_dev,
                              const float* stats_dev, uint32_t seed, float vmin, float vmax, void* stream);
 
+/* ---- label creation for the boundary method (first part) --------------------------------------------
+ * boundary_label (mode 0) / border_label (mode 1) of src/training/train_data_representations.py:75-125 for a batch of
+ * instance masks [N][H][W] (uint16): 2 = boundary / touching border, 1 = cell interior, 0 = background; exact.       */
+int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uint8_t* out, void* stream);
+
 /* ---- evaluation helpers (EvalWorker.calc_scores, src/evaluation/eval.py:248-256) -----------------
  * mseg_eval_relabel: border_correction(mask, border_width) (src/utils/utils.py:25-47: instances not visible inside the
  *   frame minus its border are deleted) followed by skimage.measure.label (8-neighbours of EQUAL value connect; new ids

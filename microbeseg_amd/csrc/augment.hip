@@ -436,3 +436,47 @@ extern "C" int mseg_aug_noise_normalize(const float* in, float* out, int N, int 
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
+
+// =====================================================================================================================
+// Label creation for the boundary method (first part): boundary_label / border_label of
+// src/training/train_data_representations.py (:75-99, :102-125).  The reference loops over the instances
+// (binary_dilation(nucleus, 3x3) ^ nucleus, OR-ed over all instances); per pixel that is a 3x3 neighbourhood rule:
+//   boundary(p) = some 8-neighbour of p carries an instance id different from label(p)  (nothing outside the image)
+//   outer(p)    = label(p) == 0 and some 8-neighbour is foreground
+//   mode 0 (boundary_label): 2 where boundary, else 1 where label > 0, else 0
+//   mode 1 (border_label):   2 where boundary XOR outer, else 1 where label > 0, else 0
+// One pass, 9 reads + 1 byte written per pixel; exact.
+__global__ void label_boundary_kernel(const uint16_t* __restrict__ mask, int N, int H, int W, int mode,
+                                      uint8_t* __restrict__ out) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = t / hw;
+    const int r = (int)(t - s * hw);
+    const int y = r / W, x = r - y * W;
+    const uint16_t* p = mask + s * hw;
+    const int lab = p[r];
+    bool other = false, anyfg = false;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const int yy = y + dy, xx = x + dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const int q = p[(size_t)yy * W + xx];
+        other |= (q > 0) & (q != lab);
+        anyfg |= q > 0;
+      }
+    const bool outer = (lab == 0) & anyfg;
+    const bool two = mode == 0 ? other : (other != outer);
+    out[t] = two ? 2 : (lab > 0 ? 1 : 0);
+  }
+}
+
+extern "C" int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uint8_t* out, void* stream) {
+  if (!mask || !out || N <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return MSEG_EINVAL;
+  hipLaunchKernelGGL(label_boundary_kernel, dim3(aug_blocks((size_t)N * H * W)), dim3(AUG_BLOCK), 0, (hipStream_t)stream,
+                     mask, N, H, W, mode, out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
