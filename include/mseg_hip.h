@@ -255,6 +255,17 @@ int mseg_aug_noise_normalize(const float* in, float* out, int N, int H, int W, c
  * instance masks [N][H][W] (uint16): 2 = boundary / touching border, 1 = cell interior, 0 = background; exact.       */
 int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uint8_t* out, void* stream);
 
+/* ---- label creation for the distance method (second part) ---------------------------------------------
+ * distance_label(label, search_radius) of src/training/train_data_representations.py:261-361 (with bottom_hat_closing
+ * :40-72) for a batch of instance masks [N][H][W] (uint16): cell_out = per-cell normalised Euclidean distance transform
+ * inside the search window around the rounded centroid; neighbor_out = neighbour distances (inverse normalised distance
+ * to the other cells of the window, gaps between close cells from the disk(3) bottom-hat transform, borders of touching
+ * cells), rescaled and closed with a 3x3 grey closing.  Both float32 [N][H][W].  ws: device scratch of at least
+ * mseg_label_distance_workspace_bytes(N, H, W) bytes (0 = unsupported shape; H, W <= 32767).                          */
+size_t mseg_label_distance_workspace_bytes(int N, int H, int W);
+int mseg_label_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float* cell_out,
+                        float* neighbor_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- evaluation helpers (EvalWorker.calc_scores, src/evaluation/eval.py:248-256) -----------------
  * mseg_eval_relabel: border_correction(mask, border_width) (src/utils/utils.py:25-47: instances not visible inside the
  *   frame minus its border are deleted) followed by skimage.measure.label (8-neighbours of EQUAL value connect; new ids

@@ -1,11 +1,14 @@
-"""Training-label creation, the part that is a pure neighbourhood rule (first part).
+"""Training-label creation on the MI355X.
 
-Mirror of ``boundary_label`` (:75-99), ``border_label`` (:102-125) and the dispatcher ``get_label`` (:12-38) of
-``src/training/train_data_representations.py``.  The reference builds both labels by looping over the instances
-(``binary_dilation(nucleus, 3x3) ^ nucleus``); on the MI355X they are ONE streaming kernel over the mask batch
-(csrc/augment.hip: ``mseg_label_boundary``), exact.  The distance labels (``distance_label``: per-cell Euclidean distance
-transforms, bottom-hat gap filling, grey closing) are not part of this build yet — ``get_label`` raises for them, as it
-does for the reference's experimental label types.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
+Mirror of ``boundary_label`` (:75-99), ``border_label`` (:102-125), ``distance_label`` (:261-361) and the dispatcher
+``get_label`` (:12-38) of ``src/training/train_data_representations.py``.  The reference builds every label by looping
+over the instances in Python (``binary_dilation(nucleus, 3x3) ^ nucleus``; per-cell crops through scipy's Euclidean
+distance transform; two binary closings per cell over the whole image).  Here the boundary / border labels are ONE
+streaming kernel over the mask batch (csrc/augment.hip: ``mseg_label_boundary``) and the distance labels a fixed sequence
+of passes over the pixel batch (csrc/labels.hip: ``mseg_label_distance``): exact integer distances by a row sweep over
+run ends, closings with the radius-3 disk, union-find gap components, per-gap moments and rim sums by atomics.
+``get_label`` raises for the reference's experimental label types (adapted_border, j4, cell_dist*), which microbeSEG's
+training never requests.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
 """
 import numpy as np
 import torch
@@ -40,13 +43,66 @@ def border_label(label):
     return _label_device(label, 1)
 
 
+def distance_label_batch(masks, search_radius):
+    """ Cell and neighbor distance labels of a batch of equally sized instance masks (N, H, W) in ONE call.
+    Returns (cell distances, neighbor distances), float32 numpy arrays (N, H, W). """
+    if not torch.cuda.is_available():
+        raise RuntimeError("microbeseg_amd label creation needs the MI355X HIP path (no CPU fallback)")
+    lib = _lib.load()
+    a = np.ascontiguousarray(masks)
+    if a.ndim != 3:
+        raise RuntimeError("expected a batch (N, H, W) of intensity-coded instance masks")
+    if a.size == 0:
+        raise RuntimeError("empty mask batch")
+    if a.min() < 0 or a.max() > 65535:
+        raise RuntimeError("instance ids must fit uint16")
+    if int(search_radius) <= 0:
+        raise RuntimeError("search_radius must be positive")
+    N, H, W = a.shape
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    cell = np.empty((N, H, W), np.float32)
+    nb = np.empty((N, H, W), np.float32)
+    step = 64                                     # images per launch sequence: bounds the per-cell tables (3 MiB / image)
+    for i in range(0, N, step):
+        n = min(step, N - i)
+        need = lib.mseg_label_distance_workspace_bytes(n, H, W)
+        if need == 0:
+            raise RuntimeError(f"unsupported mask shape {H}x{W}")
+        m = torch.from_numpy(a[i:i + n].astype(np.uint16).view(np.int16)).to(dev)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        c = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        d = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        _lib.check(lib.mseg_label_distance(m.data_ptr(), n, H, W, int(search_radius), c.data_ptr(), d.data_ptr(),
+                                           ws.data_ptr(), need, st), "label_distance")
+        cell[i:i + n] = c.cpu().numpy()
+        nb[i:i + n] = d.cpu().numpy()
+    return cell, nb
+
+
+def distance_label(label, search_radius):
+    """ Cell and neighbor distance label creation (Euclidean distance).
+
+    :param label: Intensity-coded instance segmentation label image.
+    :param search_radius: half size of the window around each cell's centroid in which its distances are computed.
+    :return: Cell distance label image, neighbor distance label image (float32).
+    """
+    a = np.asarray(label)
+    if a.ndim != 2:
+        raise RuntimeError("expected a 2-D intensity-coded instance mask")
+    cell, nb = distance_label_batch(a[None], search_radius)
+    return cell[0], nb[0]
+
+
 def get_label(mask, label_type, max_mal):
     """ Training data representation of an instance mask (reference train_data_representations.py:12-38). """
     if label_type == 'boundary':
         return boundary_label(mask)
     if label_type == 'border':
         return border_label(mask)
-    if label_type in ('adapted_border', 'j4', 'cell_dist', 'cell_dist_clipped', 'distance'):
+    if label_type == 'distance':
+        return distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)))
+    if label_type in ('adapted_border', 'j4', 'cell_dist', 'cell_dist_clipped'):
         raise RuntimeError(f"label type '{label_type}' is not part of the MI355X build yet (SURVEY.md §8f n2): create it "
                            "with the reference's train_data_representations.py")
     raise Exception('Label type not known')

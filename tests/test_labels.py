@@ -1,5 +1,6 @@
-"""Label creation of the boundary method (first part): oracle vs vectors from the real reference (CPU),
-HIP kernel vs the same vectors (GPU, exact)."""
+"""Label creation: oracle vs vectors from the real reference (CPU), HIP kernels vs the same vectors
+(GPU; exact for the boundary / border labels, 1e-6 absolute for the distance labels — integer distances and decisions are
+exact, the fp64 rescaling goes through the device's exp)."""
 import pathlib
 import sys
 
@@ -43,4 +44,80 @@ def test_hip_matches_oracle_random():
     assert np.array_equal(T.boundary_label(m), labels_ref.boundary_label(m))
     assert np.array_equal(T.border_label(m), labels_ref.border_label(m))
     with pytest.raises(RuntimeError):
-        T.get_label(m, "distance", 20)
+        T.get_label(m, "j4", 20)
+
+
+# ---- distance labels ---------------------------------------------------------------------------------------------------
+GD = np.load(ROOT / "tests" / "golden" / "labels_distance.npz")
+DCASES = sorted(k[1:] for k in GD.files if k.startswith("m"))
+DTOL = 1e-6
+
+
+def _cells(rng, H, W, n, rmin, rmax, gap):
+    """random ellipses, optionally shrunk so that narrow background gaps separate neighbours"""
+    from scipy import ndimage as ndi
+    m = np.zeros((H, W), np.uint16)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k in range(1, n + 1):
+        cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+        a, b, th = rng.uniform(rmin, rmax), rng.uniform(rmin, rmax), rng.uniform(0, np.pi)
+        u = (yy - cy) * np.cos(th) + (xx - cx) * np.sin(th)
+        v = -(yy - cy) * np.sin(th) + (xx - cx) * np.cos(th)
+        m[((u / a) ** 2 + (v / b) ** 2 <= 1) & (m == 0)] = k
+    if gap:
+        out = np.zeros_like(m)
+        for k in np.unique(m)[1:]:
+            out[ndi.binary_erosion(m == k, iterations=gap)] = k
+        m = out
+    return m
+
+
+@pytest.mark.parametrize("i", DCASES)
+def test_distance_oracle_matches_reference(i):
+    comp, weight = labels_ref.bottom_hat_closing(GD[f"m{i}"])
+    assert np.array_equal(comp > 0, GD[f"closed{i}"] > 0)
+    assert np.array_equal(weight, GD[f"corr{i}"])
+    cell, nb = labels_ref.distance_label(GD[f"m{i}"], int(GD[f"sr{i}"]))
+    assert np.array_equal(cell, GD[f"cell{i}"])
+    assert np.array_equal(nb, GD[f"neighbor{i}"])
+
+
+def test_distance_golden_covers_branches():
+    rim = sum(int((GD[f"corr{i}"] == np.float32(0.8)).sum()) for i in DCASES)
+    touching = sum(int((labels_ref.border_label(GD[f"m{i}"]) == 2).sum()) for i in DCASES)
+    assert rim > 100 and touching > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", DCASES)
+def test_distance_hip_matches_reference(i):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    cell, nb = T.distance_label(GD[f"m{i}"], int(GD[f"sr{i}"]))
+    assert cell.dtype == np.float32 and nb.dtype == np.float32
+    assert np.abs(cell - GD[f"cell{i}"]).max() <= DTOL
+    assert np.abs(nb - GD[f"neighbor{i}"]).max() <= DTOL
+
+
+@pytest.mark.gpu
+def test_distance_hip_matches_oracle_random_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    rng = np.random.default_rng(77)
+    masks = np.stack([_cells(rng, 96, 112, n, 4, 11, gap) for n, gap in ((25, 1), (12, 0), (40, 1), (6, 2), (0, 0))])
+    masks[1][masks[1] == 3] = 40000                       # ids are arbitrary uint16 values
+    masks[3][:, :4][masks[3][:, :4] > 0] = 7              # a cell in pieces along the frame
+    for sr in (9, 30):
+        cell, nb = T.distance_label_batch(masks, sr)
+        for j in range(len(masks)):
+            c, d = labels_ref.distance_label(masks[j], sr)
+            assert np.abs(cell[j] - c).max() <= DTOL, (sr, j)
+            assert np.abs(nb[j] - d).max() <= DTOL, (sr, j)
+    # get_label dispatch: search radius = ceil(0.75 * max_mal)
+    c, d = T.get_label(masks[0], "distance", 40)
+    c2, d2 = labels_ref.distance_label(masks[0], 30)
+    assert np.abs(c - c2).max() <= DTOL and np.abs(d - d2).max() <= DTOL
+    with pytest.raises(RuntimeError):
+        T.distance_label(masks, 10)
