@@ -265,6 +265,11 @@ int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uin
 size_t mseg_label_distance_workspace_bytes(int N, int H, int W);
 int mseg_label_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float* cell_out,
                         float* neighbor_out, void* ws, size_t ws_bytes, void* stream);
+/* Largest skimage regionprops major_axis_length over the cells of each mask (CreateLabelsWorker.create_labels,
+ * src/training/train.py:73-78, which sets search_radius = ceil(0.75 * ceil(max major axis))): out_dev double [N].    */
+size_t mseg_label_major_axis_workspace_bytes(int N);
+int mseg_label_max_major_axis(const uint16_t* mask, int N, int H, int W, double* out_dev, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* ---- evaluation helpers (EvalWorker.calc_scores, src/evaluation/eval.py:248-256) -----------------
  * mseg_eval_relabel: border_correction(mask, border_width) (src/utils/utils.py:25-47: instances not visible inside the

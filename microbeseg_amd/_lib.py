@@ -97,6 +97,8 @@ SIGNATURES = {
     "mseg_label_boundary": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mseg_label_distance_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_label_distance": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "mseg_label_major_axis_workspace_bytes": (_SZ, [_I]),
+    "mseg_label_max_major_axis": (_I, [_P, _I, _I, _I, _P, _P, _SZ, _P]),
     "mseg_eval_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_eval_relabel": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mseg_eval_pair_counts": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -547,3 +547,64 @@ extern "C" int mseg_label_distance(const uint16_t* mask, int N, int H, int W, in
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
+
+// ---- largest major axis length of a mask (CreateLabelsWorker.create_labels, src/training/train.py:73-78) -------------------------
+// regionprops(mask)[i].major_axis_length = 4 * sqrt(larger eigenvalue of the normalised second central moments); the label
+// creation derives the search radius of distance_label from its maximum over the cells.  Integer moment sums by atomics,
+// eigenvalue in fp64; out_dev[n] = max over the cells of image n (0 for an empty mask).
+struct LbMom {
+  unsigned long long sy, sx, syy, sxx, sxy;
+  unsigned cnt, pad;
+};
+
+__global__ void lb_cell_moments_kernel(const uint16_t* __restrict__ mask, int N, int H, int W, LbMom* __restrict__ mom) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int k = mask[t];
+    if (!k) continue;
+    const size_t s = t / hw;
+    const int r = (int)(t - s * hw);
+    const unsigned long long y = (unsigned long long)(r / W), x = (unsigned long long)(r % W);
+    LbMom* c = mom + s * LB_IDS + k;
+    atomicAdd(&c->cnt, 1u);
+    atomicAdd(&c->sy, y);
+    atomicAdd(&c->sx, x);
+    atomicAdd(&c->syy, y * y);
+    atomicAdd(&c->sxx, x * x);
+    atomicAdd(&c->sxy, x * y);
+  }
+}
+
+__global__ void lb_major_kernel(const LbMom* __restrict__ mom, int N, double* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * LB_IDS) return;
+  const LbMom g = mom[i];
+  if (!g.cnt) return;
+  const double cnt = (double)g.cnt;
+  const double a = (double)(long long)(g.cnt * g.syy - g.sy * g.sy) / (cnt * cnt);
+  const double c = (double)(long long)(g.cnt * g.sxx - g.sx * g.sx) / (cnt * cnt);
+  const double b = (double)((long long)(g.cnt * g.sxy) - (long long)(g.sx * g.sy)) / (cnt * cnt);
+  const double l1 = 0.5 * (a + c) + 0.5 * sqrt(4.0 * b * b + (a - c) * (a - c));
+  const double major = 4.0 * sqrt(fmax(l1, 0.0));
+  // non-negative doubles order like their bit patterns
+  atomicMax((unsigned long long*)(out + i / LB_IDS), (unsigned long long)__double_as_longlong(major));
+}
+
+extern "C" size_t mseg_label_major_axis_workspace_bytes(int N) {
+  return N > 0 ? (size_t)N * LB_IDS * sizeof(LbMom) : 0;
+}
+
+extern "C" int mseg_label_max_major_axis(const uint16_t* mask, int N, int H, int W, double* out_dev, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  if (!mask || !out_dev || !ws || N <= 0 || H <= 0 || W <= 0 || H > 32767 || W > 32767) return MSEG_EINVAL;
+  if (ws_bytes < mseg_label_major_axis_workspace_bytes(N)) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, mseg_label_major_axis_workspace_bytes(N), st) != hipSuccess) return MSEG_ELAUNCH;
+  if (hipMemsetAsync(out_dev, 0, (size_t)N * sizeof(double), st) != hipSuccess) return MSEG_ELAUNCH;
+  hipLaunchKernelGGL(lb_cell_moments_kernel, dim3(lb_blocks((size_t)N * H * W)), dim3(LB_BLOCK), 0, st, mask, N, H, W,
+                     (LbMom*)ws);
+  hipLaunchKernelGGL(lb_major_kernel, dim3(lb_blocks((size_t)N * LB_IDS)), dim3(LB_BLOCK), 0, st, (const LbMom*)ws, N,
+                     out_dev);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -10,7 +10,8 @@ SURVEY.md Appendix D).  Differences, all additive:
     (the reference hard-codes ``[64, 1024]``; BASELINE configs[0] needs a 2-level, 8-filter net);
   * with ``num_gpus > 1`` under torch.distributed each rank trains on its shard of the crop list, validation losses
     are summed over ranks so every rank takes identical save / early-stop decisions, and rank 0 writes the files;
-  * label creation (``CreateLabelsWorker``) and CPU augmentation are outside the hot path.
+  * ``CreateLabelsWorker`` (reference :26-112) creates the labels on the device (train_data_representations.py);
+  * the crop batch is augmented on the device in the train phase (device_augment.py).
 """
 import gc
 import os
@@ -32,6 +33,63 @@ from .. import parallel
 from .losses import get_loss
 from .ranger2020 import Ranger
 from .training_dataset import TrainingDataset, augmentors
+from .train_data_representations import get_label, max_major_axis_length
+from shutil import rmtree
+
+
+class CreateLabelsWorker(QObject):
+    """ Worker class for label creation (reference src/training/train.py:26-112): every ``mask*.tif`` of
+    ``path/{train,val}`` gets its training representation written next to it (``cell_dist_*`` + ``neighbor_dist_*`` for
+    the distance method, ``<label_type>_*`` otherwise). """
+    finished = pyqtSignal()
+    progress = pyqtSignal(int)
+    text_output = pyqtSignal(str)
+    stop_label_creation = False
+
+    def create_labels(self, path, label_type):
+        if len(list(path.glob('*'))) == 0:            # export has been stopped (folders are deleted)
+            self.progress.emit(0)
+            self.finished.emit()
+            return
+        self.text_output.emit('Create labels')
+        mask_ids_train = list((path / 'train').glob('mask*.tif'))
+        mask_ids_val = list((path / 'val').glob('mask*.tif'))
+        if len(mask_ids_val) < 2 or len(mask_ids_train) < 2:
+            self.text_output.emit("The training and the validation set should each contain at least two annotated "
+                                  "images! Stop")
+            self.progress.emit(0)
+            self.finished.emit()
+            return
+        mask_ids = mask_ids_train + mask_ids_val
+        for i, mask_id in enumerate(mask_ids):
+            QCoreApplication.processEvents()          # update to get the stop signal
+            if self.stop_label_creation:
+                self.text_output.emit("Stop label creation due to user interaction.\nDelete local folder.")
+                rmtree(str(path))
+                break
+            mask = tiff.imread(str(mask_id))
+            if label_type == 'distance':              # search radius from the largest major axis length
+                max_mal = int(np.ceil(max_major_axis_length(mask)))
+            else:
+                max_mal = 0
+            label = get_label(mask=mask, label_type=label_type, max_mal=max_mal)
+            fname = mask_id.name.split('mask_')[-1]
+            if label_type == 'distance':
+                tiff.imwrite(str(mask_id.parent / 'cell_dist_{}'.format(fname)), label[0])
+                tiff.imwrite(str(mask_id.parent / 'neighbor_dist_{}'.format(fname)), label[1])
+            else:
+                tiff.imwrite(str(mask_id.parent / '{}_{}'.format(label_type, fname)), label)
+            self.progress.emit(int(100 * (i + 1) / len(mask_ids)))
+        if self.stop_label_creation:
+            self.progress.emit(0)
+        else:
+            self.progress.emit(100)
+        self.finished.emit()
+        return
+
+    @pyqtSlot()
+    def stop_label_creation_process(self):
+        self.stop_label_creation = True
 
 
 class TrainWorker(QObject):

@@ -94,6 +94,27 @@ def distance_label(label, search_radius):
     return cell[0], nb[0]
 
 
+def max_major_axis_length(mask):
+    """ Largest ``regionprops(mask)[i].major_axis_length`` of an instance mask (what create_labels turns into max_mal,
+    reference src/training/train.py:73-78); 0.0 for an empty mask. """
+    if not torch.cuda.is_available():
+        raise RuntimeError("microbeseg_amd label creation needs the MI355X HIP path (no CPU fallback)")
+    lib = _lib.load()
+    a = np.ascontiguousarray(mask)
+    if a.ndim != 2:
+        raise RuntimeError("expected a 2-D intensity-coded instance mask")
+    if a.min(initial=0) < 0 or a.max(initial=0) > 65535:
+        raise RuntimeError("instance ids must fit uint16")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m = torch.from_numpy(a.astype(np.uint16).view(np.int16)).to(dev)
+    need = lib.mseg_label_major_axis_workspace_bytes(1)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    _lib.check(lib.mseg_label_max_major_axis(m.data_ptr(), 1, a.shape[0], a.shape[1], out.data_ptr(), ws.data_ptr(), need,
+                                             torch.cuda.current_stream().cuda_stream), "label_max_major_axis")
+    return float(out.item())
+
+
 def get_label(mask, label_type, max_mal):
     """ Training data representation of an instance mask (reference train_data_representations.py:12-38). """
     if label_type == 'boundary':

@@ -124,3 +124,19 @@ def distance_label(label, search_radius):
     nb = np.clip(1 / np.sqrt(0.65 + 0.5 * np.exp(-11 * (nb - 0.75))) - 0.19, 0, 1)
     nb = ndi.grey_closing(nb, size=(3, 3))
     return cell.astype(np.float32), nb.astype(np.float32)
+
+
+def major_axis_lengths(label):
+    """regionprops(label)[i].major_axis_length in ascending id order (the label creation takes ceil(max) as max_mal,
+    src/training/train.py:73-78): 4 * sqrt(larger eigenvalue of the normalised second central moments)"""
+    lab = np.asarray(label)
+    out = []
+    for k in np.unique(lab):
+        if k == 0:
+            continue
+        ys, xs = np.nonzero(lab == k)
+        y = ys.astype(np.float64) - ys.mean()
+        x = xs.astype(np.float64) - xs.mean()
+        a, c, b = (y * y).mean(), (x * x).mean(), (x * y).mean()
+        out.append(4.0 * np.sqrt(0.5 * (a + c) + 0.5 * np.sqrt(4 * b * b + (a - c) ** 2)))
+    return np.array(out, np.float64)

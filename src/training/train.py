@@ -1,1 +1,1 @@
-from microbeseg_amd.training.train import TrainWorker, get_max_epochs, seed_worker  # noqa: F401
+from microbeseg_amd.training.train import CreateLabelsWorker, TrainWorker, get_max_epochs, seed_worker  # noqa: F401

@@ -49,7 +49,7 @@ def test_hip_matches_oracle_random():
 
 # ---- distance labels ---------------------------------------------------------------------------------------------------
 GD = np.load(ROOT / "tests" / "golden" / "labels_distance.npz")
-DCASES = sorted(k[1:] for k in GD.files if k.startswith("m"))
+DCASES = sorted(k[1:] for k in GD.files if k.startswith("m") and k[1:].isdigit())
 DTOL = 1e-6
 
 
@@ -121,3 +121,62 @@ def test_distance_hip_matches_oracle_random_batch():
     assert np.abs(c - c2).max() <= DTOL and np.abs(d - d2).max() <= DTOL
     with pytest.raises(RuntimeError):
         T.distance_label(masks, 10)
+
+
+@pytest.mark.parametrize("i", DCASES)
+def test_major_axis_oracle_matches_reference(i):
+    mal = labels_ref.major_axis_lengths(GD[f"m{i}"])
+    ref = GD[f"mal{i}"]
+    assert mal.shape == ref.shape and np.allclose(mal, ref, rtol=1e-12, atol=0)
+    assert int(np.ceil(mal.max())) == int(np.ceil(ref.max()))
+
+
+@pytest.mark.gpu
+def test_major_axis_hip_matches_reference():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    for i in DCASES:
+        v = T.max_major_axis_length(GD[f"m{i}"])
+        assert abs(v - GD[f"mal{i}"].max()) <= 1e-9 * GD[f"mal{i}"].max()
+    assert T.max_major_axis_length(np.zeros((16, 16), np.uint16)) == 0.0
+
+
+@pytest.mark.gpu
+def test_create_labels_worker(tmp_path):
+    """CreateLabelsWorker (reference train.py:26-112): files, dtypes and values of both methods; stop handling."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.utils import synth, tiffio
+    from src.training.train import CreateLabelsWorker
+    root = synth.write_training_set(tmp_path / "set", 3, 2, size=96, seed=9, label_types=())
+    w = CreateLabelsWorker()
+    prog, msgs, done = [], [], []
+    w.progress.connect(prog.append)
+    w.text_output.connect(msgs.append)
+    w.finished.connect(lambda: done.append(1))
+    w.create_labels(root, "distance")
+    assert done == [1] and prog[-1] == 100 and msgs[0] == "Create labels"
+    for mode, n in (("train", 3), ("val", 2)):
+        for i in range(n):
+            mask = tiffio.imread(root / mode / f"mask_{i:03d}.tif")
+            sr = int(np.ceil(0.75 * int(np.ceil(labels_ref.major_axis_lengths(mask).max()))))
+            c, d = labels_ref.distance_label(mask, sr)
+            cell = tiffio.imread(root / mode / f"cell_dist_{i:03d}.tif")
+            nb = tiffio.imread(root / mode / f"neighbor_dist_{i:03d}.tif")
+            assert cell.dtype == np.float32 and nb.dtype == np.float32
+            assert np.abs(cell - c).max() <= DTOL and np.abs(nb - d).max() <= DTOL
+    w.create_labels(root, "boundary")
+    b = tiffio.imread(root / "val" / "boundary_001.tif")
+    assert b.dtype == np.uint8 and np.array_equal(b, labels_ref.boundary_label(tiffio.imread(root / "val" / "mask_001.tif")))
+    # fewer than two validation masks: message, nothing done
+    (root / "val" / "mask_001.tif").unlink()
+    prog.clear(), msgs.clear()
+    w.create_labels(root, "distance")
+    assert prog == [0] and "at least two annotated" in msgs[-1]
+    # stop request: the folder is deleted, like the reference does
+    root2 = synth.write_training_set(tmp_path / "set2", 2, 2, size=64, seed=3, label_types=())
+    w2 = CreateLabelsWorker()
+    w2.stop_label_creation_process()
+    w2.create_labels(root2, "distance")
+    assert not root2.exists()

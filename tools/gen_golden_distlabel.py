@@ -55,6 +55,9 @@ for i, (H, W, n, r0, r1, gap, sr) in enumerate(cases):
     out[f"neighbor{i}"] = nb
     out[f"closed{i}"] = closed.astype(np.int32)
     out[f"corr{i}"] = corr.astype(np.float32)
+    # the search radius of the label creation comes from the largest major axis (src/training/train.py:73-78)
+    from skimage.measure import regionprops
+    out[f"mal{i}"] = np.array([c.major_axis_length for c in regionprops(m.astype(np.int32))], np.float64)
     print(i, m.shape, "cells", len(np.unique(m)) - 1, "gaps", int(closed.max()), "cell max", float(cell.max()), "nb max",
           float(nb.max()), "nb>0 px", int((nb > 0).sum()))
 np.savez_compressed(OUT / "labels_distance.npz", **out)
