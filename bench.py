@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--norm", default="bn")
     ap.add_argument("--filters", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--optimizer", default="adam", choices=["adam", "ranger"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE configs[2]: bf16 matrix-core inputs for the 3x3 stride-1 convolutions, fp32 "
+                         "accumulate / storage / normalisation statistics (the default line is the fp32 configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracketing of MFMA kernels")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary inference (Mpixels/s) measurement")
@@ -174,8 +177,8 @@ def inference_metric(args, net, dev):
 
 
 def default_workload(args):
-    return (args.batch, args.size, args.arch, args.act, args.norm, tuple(args.filters), args.optimizer) == \
-        (32, 256, "DU", "relu", "bn", (64, 1024), "adam")
+    return (args.batch, args.size, args.arch, args.act, args.norm, tuple(args.filters), args.optimizer,
+            args.precision) == (32, 256, "DU", "relu", "bn", (64, 1024), "adam", "fp32")
 
 
 def pmc_traffic(kernel):
@@ -213,6 +216,7 @@ def main():
     from microbeseg_amd.training.losses import get_loss
 
     filters = tuple(args.filters)
+    engine.set_precision(args.precision)
     torch.manual_seed(0)
     net = build_unet(args.arch, args.act, "conv", args.norm, dev, world if world > 1 else 1,
                      ch_out=3 if args.arch == "U" else 1, filters=filters)
@@ -265,9 +269,11 @@ def main():
         "metric": "training crops/sec (256px)" if args.size == 256 else f"training crops/sec ({args.size}px)",
         "value": round(value, 3), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {args.arch}-Net distance-map training step, filters "
-                               f"{list(filters)}, {args.size}x{args.size} crops, per-GPU batch {args.batch}, fp32, "
+        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{1 if args.precision == 'fp32' else 2}]: {args.arch}-Net "
+                               f"distance-map training step, filters "
+                               f"{list(filters)}, {args.size}x{args.size} crops, per-GPU batch {args.batch}, "
+                               f"{'fp32' if args.precision == 'fp32' else 'bf16 3x3 convolutions (fp32 accumulate, fp32 storage and norm statistics)'}, "
                                f"{args.act}/{args.norm}, SmoothL1x2 + Adam(amsgrad)" if args.arch == "DU" else
                                f"{args.arch}-Net boundary training step, filters {list(filters)}, {args.size}px, "
                                f"batch {args.batch}, ce_dice + Adam",

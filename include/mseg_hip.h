@@ -70,6 +70,8 @@ typedef struct MsegSrc {
 #define MSEG_EPI_SCATTER2X2 1
 #define MSEG_MORDER_LINEAR 0
 #define MSEG_MORDER_PARITY 1 /* M ordered by (oy&1, ox&1) class first: lets stride-2 TCONV tiles skip dead taps */
+#define MSEG_PREC_F32 0
+#define MSEG_PREC_BF16 1
 
 typedef struct MsegIgemm {
   MsegSrc src[2];
@@ -81,7 +83,9 @@ typedef struct MsegIgemm {
   int32_t NB, Hi, Wi, Ho, Wo;
   int32_t KH, KW, stride, pad, mode, morder;
   int32_t Ngemm, epi, split, ld0, ld1, acc0, acc1, Cq;
-  int32_t reserved;
+  int32_t precision; /* MSEG_PREC_F32, or MSEG_PREC_BF16: bf16 matrix-core inputs, fp32 accumulate (BASELINE configs[2]) —
+                      * 3x3 stride-1 launches only (MSEG_EINVAL otherwise); `w` then points at the bf16 copy of the
+                      * packed weights (mseg_f32_to_bf16); sources, bias and destinations stay fp32 */
   /* optional split-K scratch (small batches: fewer 3x3 stride-1 tiles than workgroup slots).  ws == NULL or too small: the
    * launch simply is not split.  Size: mseg_igemm_workspace_bytes(). */
   void* ws;
@@ -89,6 +93,8 @@ typedef struct MsegIgemm {
 } MsegIgemm;
 
 int mseg_igemm(const MsegIgemm* p, void* stream);
+/* round-to-nearest-even conversion of n floats to bf16 (the packed weights of a MSEG_PREC_BF16 launch) */
+int mseg_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* bytes of split-K scratch this launch would use (0: it would not be split) */
 size_t mseg_igemm_workspace_bytes(const MsegIgemm* p);
 

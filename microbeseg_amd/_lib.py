@@ -35,7 +35,7 @@ class MsegIgemm(C.Structure):
                 ("mode", C.c_int32), ("morder", C.c_int32),
                 ("Ngemm", C.c_int32), ("epi", C.c_int32), ("split", C.c_int32), ("ld0", C.c_int32),
                 ("ld1", C.c_int32), ("acc0", C.c_int32), ("acc1", C.c_int32), ("Cq", C.c_int32),
-                ("reserved", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("precision", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class MsegWgrad(C.Structure):
@@ -55,6 +55,7 @@ _SZ = C.c_size_t
 SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
     "mseg_igemm_workspace_bytes": (_SZ, [C.POINTER(MsegIgemm)]),
+    "mseg_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -910,6 +910,213 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
 }
 
+// ---- bf16 variant of the halo kernel (BASELINE configs[2]: bf16 forward / backward, fp32 accumulate) ------------------
+// Same tiling, operands and epilogue as igemm_halo_kernel; the differences:
+//   * the (normalised, activated) source pixels are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while they are staged into
+//     LDS, the packed weights arrive as bf16 (mseg_f32_to_bf16 of the packed fp32 tensor); storage in HBM stays fp32;
+//   * v_mfma_f32_32x32x16_bf16: one instruction consumes 16 input channels (fp32 accumulate; same C layout as 32x32x2);
+//   * LDS rows are 32 bf16 = 64 B + 16 B pad (80 B stride: conflict-free ds_read_b128), tiles are at most 32 pixels wide
+//     (halo <= 204 rows), and the weights are staged one kernel ROW (3 taps) at a time, double buffered: 76 KiB for
+//     BN = 128 -> two workgroups per CU, one barrier per 12 MFMAs of a wave instead of one per tap.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define HB_STRIDE 40          // bf16 elements per LDS row
+
+template <int BN, int TR>
+__global__ __launch_bounds__(512, 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                 int chunks_per_split) {
+  constexpr int BM = 128;
+  using Cfg = HaloCfg<BN>;
+  constexpr int HMAX = 204;                          // (4 + 2) x (32 + 2), the largest halo (tw_log2 <= 5)
+  constexpr int HL = (HMAX * 8 + 511) / 512;         // float4 per thread per chunk (4)
+  constexpr int ASTAGE = HMAX * HB_STRIDE;
+  constexpr int BSTAGE = 3 * BN * HB_STRIDE;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[ASTAGE + 2 * BSTAGE];
+  __bf16* const Abuf = lds;
+  __bf16* const Bbuf = lds + ASTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = tid >> 3, scol = tid & 7;         // halo staging: 64 rows x 8 channel quads per pass
+  const int brow = tid >> 2, bcol = tid & 3;         // weight staging: 128 rows x 4 groups of 8 channels
+  const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
+  const int HROWS = (TH + 2) * HW2;
+  const int H = p.Hi, W = p.Wi;
+  const int M = p.NB * H * W;
+  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  const int lid_all = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int ntiles_all = (int)gridDim.x / ksplit;
+  const int kz = lid_all / ntiles_all;
+  const int lid = lid_all - kz * ntiles_all;
+  const int tile_m = lid / ntiles_n, tile_n = lid - tile_m * ntiles_n;
+  const int img = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - img * (tiles_x * tiles_y);
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  const bool conv = p.mode == MSEG_MODE_CONV;
+
+  int hpix[HL];
+  unsigned hvalid = 0u;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int hrow = srow + 64 * j;
+    const int hy = hrow / HW2, hx = hrow - hy * HW2;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+    hpix[j] = iy * W + ix;
+    hvalid |= (unsigned)ok << j;
+  }
+  int abase[Cfg::MB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a) {
+    const int i = wm * Cfg::TM + a * 32 + li;
+    abase[a] = ((i >> tw_log2) * HW2 + (i & (TW - 1))) * HB_STRIDE + lh * 8;
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+  const unsigned OOB = 0x80000000u;
+  const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
+  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
+                                                                        H * W * p.src[0].C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
+                                                                        H * W * C1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                        9 * p.Npad * p.Kpad * 2, 0x00020000);
+  const bool bact = brow < BN;
+  const unsigned wvoff = bact ? ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u : OOB;
+
+  float4 rh[HL], rsc, rsh;
+  f32x4 rb[3];
+  unsigned hlive = 0u;
+  int ract = 0;
+  bool cur_s1 = false;
+
+  auto issue_halo = [&](int chunk) {
+    const int c = chunk * KC + scol * 4;
+    cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
+    const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
+    const unsigned sC4 = (unsigned)s.C * 4u;
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u + scol * 16u;
+    hlive = (c < p.Cin) ? hvalid : 0u;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const bool ok = (hlive >> j) & 1u;
+      const unsigned vo = ok ? (unsigned)hpix[j] * sC4 + soff : OOB;
+      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+      rh[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const unsigned cl = (c < p.Cin) ? (unsigned)(cur_s1 ? c - C0 : c) : 0u;
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
+      rsc = *reinterpret_cast<const float4*>(scp + o);
+      rsh = *reinterpret_cast<const float4*>(shp + o);
+    }
+  };
+
+  auto commit_halo = [&](__bf16* As) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const int hrow = srow + 64 * j;
+      if (hrow < HMAX) {
+        float4 v = rh[j];
+        if (TR != 0) {
+          if (TR == 2) v = act_fwd4(v, ract);
+          else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+          const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+          v.x = (v.x * rsc.x + rsh.x) * m; v.y = (v.y * rsc.y + rsh.y) * m;
+          v.z = (v.z * rsc.z + rsh.z) * m; v.w = (v.w * rsc.w + rsh.w) * m;
+        }
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
+      }
+    }
+  };
+
+  // weights of kernel row ky of a chunk: 3 taps x [BN][32] bf16
+  auto issue_b = [&](int chunk, int ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned wso = ((unsigned)(ky * 3 + kx) * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC) * 2u;
+      rb[kx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, wso, 0));
+    }
+  };
+  auto commit_b = [&](__bf16* Bs) {
+    if (bact) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        *reinterpret_cast<f32x4*>(Bs + (kx * BN + brow) * HB_STRIDE + bcol * 8) = rb[kx];
+    }
+  };
+
+  const int c_begin = kz * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  issue_halo(c_begin);
+  issue_b(c_begin, 0);
+  commit_halo(Abuf);
+  commit_b(Bbuf);
+  __syncthreads();
+
+  int bsel = 0;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const __bf16* As = Abuf;
+    const bool more_chunks = chunk + 1 < c_end;
+    for (int ky = 0; ky < 3; ++ky) {
+      if (ky == 0 && more_chunks) issue_halo(chunk + 1);
+      // weights of the next stage (the very last stage re-reads its own: keeps the body branch-free)
+      issue_b(ky == 2 ? (more_chunks ? chunk + 1 : chunk) : chunk, ky == 2 ? (more_chunks ? 0 : 2) : ky + 1);
+      const __bf16* Bs = Bbuf + bsel * BSTAGE;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * HB_STRIDE;   // scalar
+#pragma unroll
+        for (int kk = 0; kk < KC / 16; ++kk) {
+          bf16x8 af[Cfg::MB], bf[Cfg::NB];
+#pragma unroll
+          for (int a = 0; a < Cfg::MB; ++a)
+            af[a] = *reinterpret_cast<const bf16x8*>(As + abase[a] + toff + kk * 16);
+#pragma unroll
+          for (int b = 0; b < Cfg::NB; ++b)
+            bf[b] = *reinterpret_cast<const bf16x8*>(Bs + (kx * BN + wn * Cfg::TN + b * 32 + li) * HB_STRIDE + kk * 16 +
+                                                     lh * 8);
+#pragma unroll
+          for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+      }
+      commit_b(Bbuf + (bsel ^ 1) * BSTAGE);
+      if (ky == 2 && more_chunks) {
+        __syncthreads();                 // every wave is done reading this chunk's halo
+        commit_halo(Abuf);
+      }
+      __syncthreads();
+      bsel ^= 1;
+    }
+  }
+  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
+}
+
 // out[m][n] = bias[n] + sum_k ws[k][m][n]  (fixed order), routed like the PLAIN epilogue: columns < split to dst0, the
 // rest to dst1, each with its own leading dimension and accumulate flag.  One thread per 4 columns.
 __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, size_t M, int N,
@@ -961,7 +1168,7 @@ static bool halo_geometry(const MsegIgemm& p, int BNv, int* tw_log2_out, long lo
   if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0))
     return false;
-  int tw_log2 = 6;
+  int tw_log2 = p.precision == MSEG_PREC_BF16 ? 5 : 6;             // the bf16 kernel's tiles are at most 32 wide
   while ((p.Wi & ((1 << tw_log2) - 1)) != 0) --tw_log2;           // largest power of two <= 64 dividing W
   const int TH = 128 >> tw_log2;
   const long long mt = (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
@@ -1002,6 +1209,7 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   if (p.mode != MSEG_MODE_CONV && p.mode != MSEG_MODE_TCONV) return MSEG_EINVAL;
   if (p.morder == MSEG_MORDER_PARITY && ((p.Ho | p.Wo) & 1)) return MSEG_EINVAL;
   if (p.Ngemm <= 0) return MSEG_EINVAL;
+  if (p.precision != MSEG_PREC_F32 && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
   if (p.epi == MSEG_EPI_SCATTER2X2) {
     if (p.Cq <= 0 || p.Ngemm != 4 * p.Cq || p.morder != MSEG_MORDER_LINEAR) return MSEG_EINVAL;
   } else if (p.epi == MSEG_EPI_PLAIN) {
@@ -1066,9 +1274,15 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     }
     const dim3 hgrid((unsigned)(htiles * ks));
 #define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
-    if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
+#define MSEG_HALO16(BN_, TR_) \
+  hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
+    if (p.precision == MSEG_PREC_BF16) {
+      if (wide) { if (tr == 0) MSEG_HALO16(128, 0); else if (tr == 1) MSEG_HALO16(128, 1); else MSEG_HALO16(128, 2); }
+      else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }
+    } else if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
     else      { if (tr == 0) MSEG_HALO(64, 0); else if (tr == 1) MSEG_HALO(64, 1); else MSEG_HALO(64, 2); }
 #undef MSEG_HALO
+#undef MSEG_HALO16
     MSEG_LAUNCH_CHECK();
     if (ks > 1) {
       const size_t total = (size_t)M * (size_t)(p.Ngemm >> 2);
@@ -1081,6 +1295,7 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     }
     return MSEG_OK;
   }
+  if (p.precision != MSEG_PREC_F32) return MSEG_EINVAL;            // bf16 inputs: the 3x3 stride-1 kernel only
   if (fast) {
     const int tr = plain ? 0 : (generic ? 2 : 1);
 #define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_) \
@@ -1107,6 +1322,21 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     else            { if (generic) MSEG_IGEMM_LAUNCH(128, 64, false, true); else MSEG_IGEMM_LAUNCH(128, 64, false, false); }
   }
 #undef MSEG_IGEMM_LAUNCH
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- fp32 -> bf16 (round to nearest even) ------------------------------------------------------------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (__bf16)src[i];
+}
+
+extern "C" int mseg_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+  if (!src || !dst || n == 0) return MSEG_EINVAL;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

@@ -170,10 +170,10 @@ def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
 
 
-def _halo_tile_efficient(Hi, Wi):
-    """mirror of the launcher's rule: 128-pixel halo tiles (TW = largest power of two <= 64 dividing W) are used only if
-    at least 80 % of their rows fall inside the image"""
-    tw = 64
+def _halo_tile_efficient(Hi, Wi, max_tw=64):
+    """mirror of the launcher's rule: 128-pixel halo tiles (TW = largest power of two <= 64 (bf16 kernel: 32) dividing W)
+    are used only if at least 80 % of their rows fall inside the image"""
+    tw = max_tw
     while Wi % tw:
         tw //= 2
     th = 128 // tw
@@ -183,6 +183,23 @@ def _halo_tile_efficient(Hi, Wi):
 def set_kernel_timer(t):
     global _timer
     _timer = t
+
+
+_precision = "fp32"
+
+
+def set_precision(mode):
+    """'fp32' (default; the reference's arithmetic) or 'bf16' (BASELINE configs[2]): the 3x3 stride-1 convolutions —
+    forward, data gradient and weight gradient, i.e. the bulk of the FLOPs — round their (normalised) operands to bf16 for
+    the matrix cores and accumulate in fp32.  Tensors in HBM, normalisation statistics, loss and optimizer stay fp32."""
+    global _precision
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _precision = mode
+
+
+def get_precision():
+    return _precision
 
 
 # ---- thin kernel wrappers ------------------------------------------------------------------------------------
@@ -195,10 +212,19 @@ _splitk_ws = {}      # device -> grow-only scratch of the split-K igemm launches
 
 class PackedW:
     """GEMM operand [T][Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero filled) produced by pack_weight."""
-    __slots__ = ("t", "Npad", "Kpad")
+    __slots__ = ("t", "Npad", "Kpad", "_t16")
 
     def __init__(self, t, Npad, Kpad):
         self.t, self.Npad, self.Kpad = t, Npad, Kpad
+        self._t16 = None
+
+    def bf16(self):
+        """the same operand rounded to bf16 (operand of a MSEG_PREC_BF16 launch), converted on first use"""
+        if self._t16 is None:
+            self._t16 = torch.empty(self.t.numel(), dtype=torch.bfloat16, device=self.t.device)
+            check(_lib.load().mseg_f32_to_bf16(self.t.data_ptr(), self._t16.data_ptr(), self.t.numel(), _stream()),
+                  "f32_to_bf16")
+        return self._t16
 
 
 def pack_weight(src, T, R, Cc, st, sr, sc, merge_taps=False):
@@ -218,17 +244,29 @@ def pack_weight(src, T, R, Cc, st, sr, sc, merge_taps=False):
     return PackedW(dst, npad, kpad)
 
 
+def _bf16_launch(srcs, w, Hi, Wi, Ho, Wo, KH, KW, stride, pad, epi, morder):
+    """does this launch take the bf16 3x3 stride-1 kernel in bf16 mode?  (mirror of mseg_igemm's halo preconditions)"""
+    if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi and Wo == Wi and epi == EPI_PLAIN and
+            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32)):
+        return False
+    common = 9 * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
+    return common and all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+
+
 def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, dst0, ld0, acc0=0,
-          dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, real_cin=None):
+          dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, real_cin=None,
+          precision=None):
     lib = _lib.load()
     p = MsegIgemm()
+    bf16 = (precision or _precision) == "bf16" and _bf16_launch(srcs, w, Hi, Wi, Ho, Wo, KH, KW, stride, pad, epi, morder)
     for i, s in enumerate(srcs):
         p.src[i] = s
     p.nsrc = len(srcs)
     p.Cin = sum(s.C for s in srcs)
     p.Kpad = w.Kpad
     p.Npad = w.Npad
-    p.w = w.t.data_ptr()
+    p.w = w.bf16().data_ptr() if bf16 else w.t.data_ptr()
+    p.precision = 1 if bf16 else 0
     p.bias = _ptr(bias)
     p.dst0 = dst0.data_ptr()
     p.dst1 = _ptr(dst1)
@@ -250,12 +288,14 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
-    e0, e1 = _timer.bracket(_igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
-                                               halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
-                                                        and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
-                                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi)),
-                                               parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)),
-                            flops)
+    name = _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
+                              halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
+                                       and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
+                                       and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
+                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0))
+    if bf16:
+        name = name.replace("igemm_halo_kernel", "igemm_halo_bf16_kernel")
+    e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()

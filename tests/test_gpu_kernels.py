@@ -389,3 +389,66 @@ def test_split_k_halo_launches(eng, N, Cin, Cout, H, W, two_src):
               dst1=d1, ld1=Cin - c0, acc1=0, split=c0)
     assert rel_err(d0.cpu(), refn[..., :c0] + base[..., :c0]) < TOL
     assert rel_err(d1.cpu(), refn[..., c0:]) < TOL
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,two_src", [(2, 64, 64, 16, 32, False), (1, 96, 160, 32, 40, False),
+                                                     (2, 128, 64, 16, 16, True), (1, 256, 256, 16, 16, False),
+                                                     (1, 40, 24, 32, 20, False), (3, 64, 128, 30, 64, False)])
+def test_bf16_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
+    """MSEG_PREC_BF16 launches (BASELINE configs[2]): operands rounded to bf16 (RNE) while staged, fp32 accumulate.
+    Reference = torch fp32 convolution of the bf16-rounded operands; what is left is the accumulation order and, for
+    norm-on-load sources, a rare different rounding of an operand whose fp32 value differs in the last bit -> 5e-4."""
+    g = torch.Generator().manual_seed(300 + Cin + H)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1.0, rnd(g, Cin) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z, "relu", scale, shift, False)), _bf(w), b, padding=1)
+    exact = F.conv2d(_transform_cpu(z, "relu", scale, shift, False), w, b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    if two_src:
+        c0 = Cin // 2
+        n0 = _mk_node(eng, z[:, :c0], "relu", scale[:c0], shift[:c0])
+        n1 = _mk_node(eng, z[:, c0:], "relu", scale[c0:], shift[c0:])
+        srcs = [n0.src(), n1.src()]
+    else:
+        node = _mk_node(eng, z, "relu", scale, shift)
+        srcs = [node.src()]
+    assert eng._bf16_launch(srcs, wp, H, W, H, W, 3, 3, 1, 1, eng.EPI_PLAIN, eng.MORDER_LINEAR)
+    eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+    got = nchw(out.cpu())
+    assert rel_err(got, ref) < 5e-4
+    assert 1e-4 < rel_err(got, exact) < 2e-2            # it really is the bf16 path, and a sane one
+    # data gradient (plain operand): accumulate into destination 0, plain store into destination 1
+    gy = rnd(g, N, Cout, H, W)
+    refn = nhwc(F.conv_transpose2d(_bf(gy), _bf(w), None, padding=1))
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    base = rnd(g, N, H, W, Cin)
+    c0 = (Cin // 2 + 3) // 4 * 4
+    d0, d1 = base[..., :c0].contiguous().cuda(), torch.full((N, H, W, Cin - c0), float("nan"), device="cuda")
+    dz = nhwc(gy).cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, c0, acc0=1,
+              dst1=d1, ld1=Cin - c0, acc1=0, split=c0, precision="bf16")
+    assert rel_err(d0.cpu(), refn[..., :c0] + base[..., :c0]) < 1e-4
+    assert rel_err(d1.cpu(), refn[..., c0:]) < 1e-4
+
+
+def test_bf16_rejected_for_other_shapes(eng):
+    """bf16 inputs exist for the 3x3 stride-1 kernel only: the C ABI refuses anything else instead of silently
+    computing in another precision (the engine never asks for it: it keeps such layers in fp32)."""
+    from microbeseg_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    x = rnd(g, 1, 16, 16, 32).cuda()
+    w = eng.pack_weight(rnd(g, 32, 32, 3, 3).cuda(), 9, 32, 32, 1, 32 * 9, 9)
+    out = torch.empty((1, 8, 8, 32), device="cuda")
+    p = _lib.MsegIgemm()
+    p.src[0] = eng.plain_src(x, 32)
+    p.nsrc, p.Cin, p.Kpad, p.Npad, p.w = 1, 32, w.Kpad, w.Npad, w.bf16().data_ptr()
+    p.dst0 = out.data_ptr()
+    p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad = 1, 16, 16, 8, 8, 3, 3, 2, 1
+    p.Ngemm, p.split, p.ld0, p.precision = 32, 32, 32, 1
+    assert _lib.load().mseg_igemm(C.byref(p), torch.cuda.current_stream().cuda_stream) == -1
