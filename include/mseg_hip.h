@@ -113,6 +113,9 @@ typedef struct MsegWgrad {
   int32_t KH, KW, stride, pad;
   int32_t splits; /* 0 = choose */
   int32_t phase;  /* 0 = partial + reduce, 1 = split-K partial kernel only, 2 = reduction only (profiling) */
+  int32_t precision; /* MSEG_PREC_F32, or MSEG_PREC_BF16: P and Q rounded to bf16 for the matrix cores, fp32 accumulate —
+                      * 3x3 stride-1 weight gradients with a plain P only (MSEG_EINVAL otherwise) */
+  int32_t reserved;
 } MsegWgrad;
 
 size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);

@@ -43,7 +43,7 @@ class MsegWgrad(C.Structure):
                 ("nq", C.c_int32), ("Nch", C.c_int32), ("Nch_store", C.c_int32),
                 ("NB", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32), ("Hq", C.c_int32), ("Wq", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("splits", C.c_int32), ("phase", C.c_int32)]
+                ("splits", C.c_int32), ("phase", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -627,6 +627,224 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   }
 }
 
+// =====================================================================================================================
+// bf16 variant of the halo kernel (BASELINE configs[2]; MsegWgrad.precision == MSEG_PREC_BF16).
+// The contraction of a weight gradient runs over PIXELS, while the tensors are channel-contiguous (NHWC): the matrix cores
+// want every lane to hold 8 consecutive pixels of one channel.  gfx950's transposing LDS read (ds_read_b64_tr_b16) does
+// that for free: P and Q are staged exactly as they arrive — [pixel][32 channels] bf16 rows of 64 B, two such planes per
+// 64-channel tile (conflict-free for the transposed reads) — and a lane group of 16 reads a 4-pixel x 16-channel block
+// column-major.  A tap shift is a ROW offset of the Q halo image, so one (TH + 2) x (TW + 2) halo serves all nine taps:
+// a workgroup (4 waves, 32 x 32 channels each) owns a 64 x 64 channel tile for ALL 9 taps (9 x 16 accumulator registers)
+// and walks 64-pixel blocks (8 x 8, or 16 x 4 when the row length is no multiple of 8): 36 v_mfma_f32_32x32x16_bf16 per
+// wave and block against 11 staged float4 per thread — three times the arithmetic intensity of the fp32 kernel, which
+// the 16x faster matrix pipe needs.  Operands are rounded to bf16 (RNE) after the norm-on-load transform; fp32 accumulate.
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+#define WB_PIX 64
+
+__device__ __forceinline__ wbf16x8 wb_tr_read8(const __bf16* lo, const __bf16* hi) {
+  const ws16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)lo);
+  const ws16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)hi);
+  ws16x8 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  return __builtin_bit_cast(wbf16x8, v);
+}
+
+template <int TWL, int QTR>
+__global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad p, int splits, int steps_per_split) {
+  constexpr int TW = 1 << TWL, TH = WB_PIX >> TWL, QW = TW + 2, QH = TH + 2;
+  constexpr int QROWS = QH * QW;                       // 100 (8 x 8 blocks) or 108 (16 x 4)
+  constexpr int NP = WB_PIX / 16, NQ = (QROWS + 15) / 16;
+  constexpr int PEL = 2 * WB_PIX * 32, QEL = 2 * QROWS * 32;
+  constexpr int STAGE = PEL + QEL;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Mch = p.P.C, Nch = p.Nch;
+  const int ntiles_n = (Nch + 63) / 64;
+  const int ntiles = ((Mch + 63) / 64) * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int tile = lid % ntiles;
+  const int split = lid / ntiles;
+  const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
+
+  const int bx = p.Wp >> TWL, by = (p.Hp + TH - 1) / TH;
+  const int steps_img = bx * by;
+  const int steps_total = p.NB * steps_img;
+  const int step_begin = split * steps_per_split;
+  int step_end = step_begin + steps_per_split;
+  if (step_end > steps_total) step_end = steps_total;
+  const int nsteps = step_end > step_begin ? step_end - step_begin : 0;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int spx = tid >> 4, sc4 = tid & 15;
+  const int mc = mt * 64 + sc4 * 4;
+  const int qc = nt * 64 + sc4 * 4;
+  const bool q1 = (p.nq > 1) && (nt * 64 >= p.Q[0].C);
+  const MsegSrc& qs = q1 ? p.Q[1] : p.Q[0];
+  const bool mvalid = mc < Mch, qvalid = qc < Nch;
+  const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
+  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
+  const unsigned OOB = 0x80000000u;
+  const int HWp = p.Hp * p.Wp;
+  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWp * qs.C * 4, 0x00020000);
+  int desc_n = 0;
+  float4 qsc, qsh;
+  {
+    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
+    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
+    qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
+  }
+  const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+
+  int sn = step_begin / steps_img;
+  const int srem0 = step_begin - sn * steps_img;
+  int spy = (srem0 / bx) * TH, spx0 = (srem0 - (srem0 / bx) * bx) * TW;
+  // per-thread constants: P rows k = spx + 16 i (block pixel (k / TW, k % TW)), Q halo rows s = spx + 16 i
+  int pr[NP];
+  unsigned pv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int k = spx + 16 * i;
+    pr[i] = k >> TWL;
+    pv[i] = (unsigned)(pr[i] * p.Wp + (k & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
+  }
+  int qr[NQ], qj[NQ];
+  unsigned qv[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int sidx = spx + 16 * i;
+    qr[i] = sidx / QW; qj[i] = sidx - qr[i] * QW;
+    qv[i] = (unsigned)(qr[i] * p.Wq + qj[i]) * qC4 + qcl4;
+  }
+  // LDS element offsets of this thread's staging writes: plane (sc4 >> 3), row, 4 channels at (sc4 & 7) * 4
+  const int wplane = sc4 >> 3, wcol = (sc4 & 7) * 4;
+  // transposed-read addresses: lane 4q + pp of a 16-lane group supplies row q, channels 4 pp .. 4 pp + 3 of its block;
+  // the group (lane >> 4) & 1 takes channels 16 .. 31 of the wave's 32, the half lane >> 5 the pixels 8 .. 15 of a k-step
+  const int tq = (lane >> 2) & 3, tp = lane & 3, tcb = (lane >> 4) & 1;
+  const int a_lane = (wm * WB_PIX + 8 * lh + tq) * 32 + tcb * 16 + tp * 4;
+  const int b_lane = PEL + (wn * QROWS + (TWL == 3 ? lh * QW : 2 * lh * QW) + tq) * 32 + tcb * 16 + tp * 4;
+
+  float4 rp[NP], rq[NQ];
+  float qm[NQ];
+  const bool q_ps = QTR && qs.scale && qs.ss != 0;
+  int tab_n = -1;
+
+  auto issue = [&](int step) {
+    const bool live = step < nsteps;
+    if (q_ps && live && sn != tab_n) {
+      tab_n = sn;
+      qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+    }
+    if (live && sn != desc_n) {
+      desc_n = sn;
+      rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr + (size_t)sn * HWp * Mch), 0, HWp * Mch * 4,
+                                              0x00020000);
+      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWp * qs.C), 0, HWp * qs.C * 4,
+                                              0x00020000);
+    }
+    const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool pok = live & mvalid & (spy + pr[i] < p.Hp);
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv[i] : OOB, psoff, 0));
+      rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const int qy0 = spy - p.pad, qx0 = spx0 - p.pad;
+    const unsigned sb = (unsigned)(qy0 * p.Wq + qx0) * qC4;                      // wraps by design (halo rows < 0)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const bool qlive = spx + 16 * i < QROWS;
+      const int qy = qy0 + qr[i], qx = qx0 + qj[i];
+      const bool ok = live & qvalid & qlive & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
+      const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? sb + qv[i] : OOB, 0, 0));
+      rq[i] = make_float4(q[0], q[1], q[2], q[3]);
+      if (QTR) qm[i] = ok ? 1.f : 0.f;
+    }
+    spx0 += TW;
+    if (spx0 >= p.Wp) { spx0 = 0; spy += TH; if (spy >= p.Hp) { spy = 0; sn += 1; } }
+  };
+
+  auto to_bf = [](const float4& v) -> wbf16x4 {
+    wbf16x4 h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    return h;
+  };
+
+  auto commit = [&](__bf16* stage) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      *reinterpret_cast<wbf16x4*>(stage + (wplane * WB_PIX + spx + 16 * i) * 32 + wcol) = to_bf(rp[i]);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if (spx + 16 * i < QROWS) {
+        float4 v = rq[i];
+        if (QTR != 0) {
+          if (QTR == 2) v = act_fwd4(v, qs.act);
+          else { v.x = clamp_lo(v.x, qlo); v.y = clamp_lo(v.y, qlo); v.z = clamp_lo(v.z, qlo); v.w = clamp_lo(v.w, qlo); }
+          v.x = (v.x * qsc.x + qsh.x) * qm[i]; v.y = (v.y * qsc.y + qsh.y) * qm[i];
+          v.z = (v.z * qsc.z + qsh.z) * qm[i]; v.w = (v.w * qsc.w + qsh.w) * qm[i];
+        }
+        *reinterpret_cast<wbf16x4*>(stage + PEL + (wplane * QROWS + spx + 16 * i) * 32 + wcol) = to_bf(v);
+      }
+    }
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    commit(lds);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    issue(step + 1);
+    const __bf16* st = lds + buf * STAGE;
+    const __bf16* ap = st + a_lane;
+    const __bf16* bp = st + b_lane;
+#pragma unroll
+    for (int s4 = 0; s4 < WB_PIX / 16; ++s4) {
+      // pixels k0 = 16 s4 + 8 lh (+4): P rows are the block pixels in order
+      const wbf16x8 a = wb_tr_read8(ap + (16 * s4) * 32, ap + (16 * s4 + 4) * 32);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          // halo row of pixel k0 for tap (ky, kx): ((k0 / TW) + ky) * QW + k0 % TW + kx; the lane part is in b_lane
+          const int r0 = TWL == 3 ? (2 * s4 + ky) * QW + kx : (4 * s4 + ky) * QW + kx;
+          const int r1 = TWL == 3 ? r0 + 4 : r0 + QW;
+          const wbf16x8 b = wb_tr_read8(bp + r0 * 32, bp + r1 * 32);
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ky * 3 + kx], 0, 0, 0);
+        }
+    }
+    commit(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int n = nt * 64 + wn * 32 + li;
+  if (n < Nch) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < Mch) p.ws[(((size_t)split * 9 + t) * Mch + m) * Nch + n] = acc[t][r];
+      }
+    }
+  }
+}
+
 // dst[(m*Nst + n)*T + t] = sum_s ws[((s*T + t)*Mch + m)*Nch + n]   (fixed order -> deterministic)
 // A workgroup owns one m and NL = 256 / KG consecutive n, i.e. a CONTIGUOUS run of NL * T floats of dst: the T taps of
 // an (m, n) are summed together (T accumulators per thread, split range strided over KG thread groups), combined through
@@ -709,6 +927,16 @@ static WgradSel wgrad_select(const MsegWgrad& p) {
     if ((long long)p.Hq * p.Wq * p.Q[i].C * 4 >= 0x80000000LL) image_fits = false;
   }
   const bool concat_ok = !(p.nq > 1 && (p.Q[0].C % 64));
+  if (p.precision == MSEG_PREC_BF16) {
+    // bf16 halo kernel: 64-pixel blocks, 8 x 8 or (row length no multiple of 8) 16 x 4; same 80 % rule
+    w.tw_log2 = (p.Wp % 8) == 0 ? 3 : 2;
+    const int TH = 64 >> w.tw_log2;
+    const bool ok16 = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Hq == p.Hp && p.Wq == p.Wp &&
+                      (p.Wp % 4) == 0 && w.ptr == 0 && image_fits && pix_ok && concat_ok &&
+                      (long long)p.Hp * 5 >= (long long)((p.Hp + TH - 1) / TH) * TH * 4;
+    w.kind = ok16 ? 3 : -1;                            // -1: the launch is refused (the engine keeps such layers fp32)
+    return w;
+  }
   halo = halo && image_fits && pix_ok && concat_ok;
   const bool fast = halo || (whole_fits && pix_ok && concat_ok &&
                              (!w.per_sample || ((long long)p.Hp * p.Wp) % WG_PIX == 0));
@@ -721,12 +949,17 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   if (Ptot <= 0) return MSEG_EINVAL;
   long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
   const WgradSel sel = wgrad_select(p);
+  if (sel.kind < 0) return MSEG_EINVAL;
   if (sel.kind == 2) {
     const int TH = WG_PIX >> sel.tw_log2;
     steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks (wgrad_halo_kernel)
   }
+  if (sel.kind == 3) {
+    const int TH = 64 >> sel.tw_log2;
+    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // 64-pixel blocks, all 9 taps
+  }
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
-  const int per_split_wgs = tiles * p.KH;
+  const int per_split_wgs = sel.kind == 3 ? tiles : tiles * p.KH;
   // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs
   long long s = p.splits > 0 ? p.splits : (768 + per_split_wgs - 1) / per_split_wgs;
   if (s > steps_total) s = steps_total;
@@ -748,6 +981,7 @@ static int wgrad_check(const MsegWgrad& p) {
   if (csum != p.Nch || p.Nch_store <= 0 || p.Nch_store > p.Nch) return MSEG_EINVAL;
   if (!((p.KH == 3 && p.KW == 3) || (p.KH == 2 && p.KW == 2))) return MSEG_EINVAL;
   if (p.NB <= 0 || p.Hp <= 0 || p.Wp <= 0 || p.Hq <= 0 || p.Wq <= 0 || p.stride < 1) return MSEG_EINVAL;
+  if (p.precision != MSEG_PREC_F32 && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
   return MSEG_OK;
 }
 
@@ -771,7 +1005,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     const WgradSel sel = wgrad_select(p);
     const bool generic = sel.generic_act, per_sample = sel.per_sample;
     const int ptr = sel.ptr, qtr = sel.qtr, tw_log2 = sel.tw_log2;
-    const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)p.KH), block(256);
+    const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)(sel.kind == 3 ? 1 : p.KH)), block(256);
     if (sel.kind != 0) {
       static bool ident_ready[64] = {false};
       int devid = 0;
@@ -781,7 +1015,14 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
         MSEG_LAUNCH_CHECK();
         ident_ready[devid] = true;
       }
-      if (sel.kind == 2) {
+      if (sel.kind == 3) {
+#define MSEG_WB(T_, Q_) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB_Q(T_) do { if (qtr == 0) MSEG_WB(T_, 0); else if (qtr == 1) MSEG_WB(T_, 1); else MSEG_WB(T_, 2); } while (0)
+        if (tw_log2 == 3) MSEG_WB_Q(3); else MSEG_WB_Q(2);
+#undef MSEG_WB_Q
+#undef MSEG_WB
+        MSEG_LAUNCH_CHECK();
+      } else if (sel.kind == 2) {
 #define MSEG_WH(T_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_WH_Q(T_) do { if (qtr == 0) MSEG_WH(T_, 0); else if (qtr == 1) MSEG_WH(T_, 1); else MSEG_WH(T_, 2); } while (0)
         if (tw_log2 == 5) MSEG_WH_Q(5); else if (tw_log2 == 4) MSEG_WH_Q(4); else if (tw_log2 == 3) MSEG_WH_Q(3); else MSEG_WH_Q(2);

@@ -301,9 +301,25 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     e1.record()
 
 
-def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None):
+def _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad):
+    """does this weight gradient take the bf16 kernel in bf16 mode?  (mirror of wgrad_select in csrc/wgrad.hip)"""
+    if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Hq == Hp and Wq == Wp and Wp % 4 == 0 and _tr_of(P) == 0):
+        return False
+    th = 8 if Wp % 8 == 0 else 16
+    if Hp * 5 < ((Hp + th - 1) // th) * th * 4:
+        return False
+    if len(Qs) > 1 and Qs[0].C % 64:
+        return False
+    if NB * Hp * Wp + 2048 * 32 >= 2 ** 31 - 1:
+        return False
+    return Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
+
+
+def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None, precision=None):
     lib = _lib.load()
     p = MsegWgrad()
+    bf16 = (precision or _precision) == "bf16" and _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad)
+    p.precision = 1 if bf16 else 0
     p.P = P
     for i, s in enumerate(Qs):
         p.Q[i] = s
@@ -322,7 +338,10 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
         check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
         return
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
-    e0, e1 = _timer.bracket(_wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride), flops)
+    name = _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride)
+    if bf16:
+        name = "wgrad_halo_bf16_kernel<%d, %d>" % (3 if Wp % 8 == 0 else 2, max(_tr_of(s) for s in Qs))
+    e0, e1 = _timer.bracket(name, flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")

@@ -452,3 +452,37 @@ def test_bf16_rejected_for_other_shapes(eng):
     p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad = 1, 16, 16, 8, 8, 3, 3, 2, 1
     p.Ngemm, p.split, p.ld0, p.precision = 32, 32, 32, 1
     assert _lib.load().mseg_igemm(C.byref(p), torch.cuda.current_stream().cuda_stream) == -1
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,two_src,act", [(2, 64, 64, 16, 16, False, "relu"), (3, 72, 40, 16, 12, False, "relu"),
+                                                        (2, 128, 96, 24, 32, True, "relu"), (1, 64, 128, 40, 40, False, "mish"),
+                                                        (2, 32, 64, 30, 20, False, "none"), (4, 64, 64, 32, 32, False, "relu")])
+def test_bf16_halo_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
+    """MSEG_PREC_BF16 weight gradient of a 3x3 stride-1 conv: dz and the (normalised) conv input rounded to bf16,
+    fp32 accumulate over all pixels.  Reference = torch fp32 weight gradient of the rounded operands."""
+    g = torch.Generator().manual_seed(500 + Cin + W)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1, rnd(g, Cin) * 0.1
+    plain = act == "none"
+    xin = z if plain else _transform_cpu(z, act, scale, shift, False)
+    gy = rnd(g, N, Cout, H, W)
+    ref = torch.nn.grad.conv2d_weight(_bf(xin), (Cout, Cin, 3, 3), _bf(gy), padding=1)
+    exact = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, 3, 3), gy, padding=1)
+    if two_src:
+        c0 = 64
+        keep = [_mk_node(eng, z[:, :c0], act, scale[:c0], shift[:c0]), _mk_node(eng, z[:, c0:], act, scale[c0:], shift[c0:])]
+        qs = [k.src() for k in keep]
+    elif plain:
+        keep = nhwc(z).cuda()                            # the descriptors hold raw pointers: keep the tensors alive
+        qs = [eng.plain_src(keep, Cin)]
+    else:
+        keep = _mk_node(eng, z, act, scale, shift, False)
+        qs = [keep.src()]
+    dz = nhwc(gy).cuda()
+    P = eng.plain_src(dz, Cout)
+    assert eng._wgrad_bf16_ok(P, qs, N, H, W, H, W, 3, 3, 1, 1)
+    dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    ws = eng.Workspace(torch.device("cuda"))
+    eng.wgrad(P, qs, dW, N, H, W, H, W, 3, 3, 1, 1, ws, precision="bf16")
+    assert rel_err(dW.cpu(), ref) < 5e-4
+    assert 1e-5 < rel_err(dW.cpu(), exact) < 2e-2
