@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide: dense bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF)
 # forward GFLOP per 256x256 crop, measured by hooking the reference modules (SURVEY.md §8d / BASELINE.md §2)
 FWD_GFLOP_256 = {("DU", (64, 1024)): 163.30, ("U", (64, 1024)): 101.03}
 
@@ -287,9 +288,10 @@ def main():
         kernels = prof.summary()
         if kernels:
             dom = max(kernels.values(), key=lambda k: k["total_ms"])
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
-                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(dom["tflops"] / peak, 4), "traffic": None,
                                "avg_launch_ms": round(dom["avg_ms"], 4), "launches": dom["launches"]}
             if default_workload(args):
                 out["roofline"].update(pmc_traffic(dom["kernel"]))

@@ -175,3 +175,69 @@ def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch
     for k, v in net.state_dict().items():
         if "running" in k:
             assert rel_err(v.cpu(), p32[k]) < 1e-4, k
+
+
+def _bf16_rule(xs, ws):
+    """which of (forward, data gradient, weight gradient) of a 3x3 stride-1 conv the engine runs with bf16 operands:
+    mirror of engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32)"""
+    from microbeseg_amd import engine
+    _, cin, H, W = xs
+    if cin <= 4:
+        return (False, False, False)
+    ig = W % 4 == 0 and engine._halo_tile_efficient(H, W, 32)
+    th = 8 if W % 8 == 0 else 16
+    wg = W % 4 == 0 and H * 5 >= ((H + th - 1) // th) * th * 4
+    return (ig, ig, wg)
+
+
+@pytest.mark.parametrize("ut,act,norm,filters,size,batch", [("DU", "elu", "bn", (64, 128), 64, 2),
+                                                            ("U", "mish", "bn", (64, 128), 48, 3)])
+def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev):
+    """BASELINE configs[2] (bf16 forward / backward, fp32 accumulate and norm statistics): engine.set_precision('bf16')
+    against the oracle with the SAME rounding points (oracle/unet_ref.py BF16_RULE: operands of the 3x3 stride-1
+    convolutions rounded to bf16, everything else fp32).  bf16 has its own tolerance: an operand whose fp32 value differs in
+    the last bits between the two implementations can round to a different bf16 neighbour (2^-8 relative), so the
+    agreement is ~1e-3 on the outputs — a quarter of the distance between bf16 and fp32 arithmetic itself, which is also
+    checked (the bf16 path must stay within 3e-2 of the fp32 reference arithmetic)."""
+    from microbeseg_amd import engine
+    from microbeseg_amd.utils.unets import build_unet
+    from oracle import unet_ref
+    torch.manual_seed(1234)
+    ch_out = 3 if ut == "U" else 1
+    net = build_unet(ut, act, "conv", norm, dev, 1, ch_out=ch_out, filters=filters)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(batch, 1, size, size) * 2 - 1
+    net.train()
+    engine.set_precision("bf16")
+    try:
+        outs = net(x.to(dev))
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        gos = [torch.randn(o.shape) for o in outs]
+        torch.autograd.backward(outs, [g.to(dev) for g in gos])
+    finally:
+        engine.set_precision("fp32")
+
+    def oracle(rule):
+        unet_ref.BF16_RULE = rule
+        try:
+            params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                      for k, v in sd.items()}
+            ref = unet_ref.unet_forward(params, x, ut, act, norm, filters, training=True, update_running_stats=True)
+            ref = ref if isinstance(ref, tuple) else (ref,)
+            torch.autograd.backward(ref, gos)
+        finally:
+            unet_ref.BF16_RULE = None
+        return params, ref
+
+    p16, r16 = oracle(_bf16_rule)
+    p32, r32 = oracle(None)
+    for o, a, b in zip(outs, r16, r32):
+        assert rel_err(o.detach().cpu(), a.detach()) < 5e-3
+        assert 1e-4 < rel_err(o.detach().cpu(), b.detach()) < 3e-2        # really bf16, and a sane bf16
+    floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
+    for k, p in net.named_parameters():
+        if p32[k].grad.abs().max().item() <= floor:
+            continue
+        noise = _l2_rel(p16[k].grad, p32[k].grad)                          # what bf16 rounding itself does to this gradient
+        assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(2e-2, noise), k
+        assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(4e-2, 2 * noise), k
