@@ -928,12 +928,12 @@ static WgradSel wgrad_select(const MsegWgrad& p) {
   }
   const bool concat_ok = !(p.nq > 1 && (p.Q[0].C % 64));
   if (p.precision == MSEG_PREC_BF16) {
-    // bf16 halo kernel: 64-pixel blocks, 8 x 8 or (row length no multiple of 8) 16 x 4; same 80 % rule
+    // bf16 halo kernel: 64-pixel blocks, 8 x 8 or (row length no multiple of 8) 16 x 4; used down to 50 % live block rows
     w.tw_log2 = (p.Wp % 8) == 0 ? 3 : 2;
     const int TH = 64 >> w.tw_log2;
     const bool ok16 = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Hq == p.Hp && p.Wq == p.Wp &&
                       (p.Wp % 4) == 0 && w.ptr == 0 && image_fits && pix_ok && concat_ok &&
-                      (long long)p.Hp * 5 >= (long long)((p.Hp + TH - 1) / TH) * TH * 4;
+                      (long long)p.Hp * 2 >= (long long)((p.Hp + TH - 1) / TH) * TH;     // >= 50 % of the block rows
     w.kind = ok16 ? 3 : -1;                            // -1: the launch is refused (the engine keeps such layers fp32)
     return w;
   }

@@ -172,11 +172,13 @@ def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
 
 def _halo_tile_efficient(Hi, Wi, max_tw=64):
     """mirror of the launcher's rule: 128-pixel halo tiles (TW = largest power of two <= 64 (bf16 kernel: 32) dividing W)
-    are used only if at least 80 % of their rows fall inside the image"""
+    are used only if at least 80 % (bf16 kernel: 50 %) of their rows fall inside the image"""
     tw = max_tw
     while Wi % tw:
         tw //= 2
     th = 128 // tw
+    if max_tw == 32:
+        return Hi * 2 >= ((Hi + th - 1) // th) * th
     return Hi * 5 >= ((Hi + th - 1) // th) * th * 4
 
 
@@ -244,13 +246,19 @@ def pack_weight(src, T, R, Cc, st, sr, sc, merge_taps=False):
     return PackedW(dst, npad, kpad)
 
 
-def _bf16_launch(srcs, w, Hi, Wi, Ho, Wo, KH, KW, stride, pad, epi, morder):
-    """does this launch take the bf16 3x3 stride-1 kernel in bf16 mode?  (mirror of mseg_igemm's halo preconditions)"""
-    if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi and Wo == Wi and epi == EPI_PLAIN and
-            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32)):
-        return False
-    common = 9 * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
-    return common and all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+def _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, morder):
+    """which bf16 kernel a launch takes in bf16 mode: 'halo' (3x3 stride 1), 'fast' (the gather kernel: stride-2
+    convolutions, ConvTranspose as a GEMM, their data gradients) or None = stays fp32 (mirror of mseg_igemm's dispatch)"""
+    common = KH <= 4 and KW <= 4 and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
+    if not common:
+        return None
+    if (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi and Wo == Wi and epi == EPI_PLAIN and
+            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32) and
+            all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)):
+        return "halo"
+    fast = (mode == MODE_CONV or stride == 1 or (morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)) and \
+        all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+    return "fast" if fast else None
 
 
 def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, dst0, ld0, acc0=0,
@@ -258,7 +266,8 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
           precision=None):
     lib = _lib.load()
     p = MsegIgemm()
-    bf16 = (precision or _precision) == "bf16" and _bf16_launch(srcs, w, Hi, Wi, Ho, Wo, KH, KW, stride, pad, epi, morder)
+    bf16 = _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, morder) \
+        if (precision or _precision) == "bf16" else None
     for i, s in enumerate(srcs):
         p.src[i] = s
     p.nsrc = len(srcs)
@@ -294,7 +303,8 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
                               parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0))
     if bf16:
-        name = name.replace("igemm_halo_kernel", "igemm_halo_bf16_kernel")
+        name = name.replace("igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel",
+                                                                                  "igemm_fast_bf16_kernel")
     e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
@@ -306,7 +316,7 @@ def _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad):
     if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Hq == Hp and Wq == Wp and Wp % 4 == 0 and _tr_of(P) == 0):
         return False
     th = 8 if Wp % 8 == 0 else 16
-    if Hp * 5 < ((Hp + th - 1) // th) * th * 4:
+    if Hp * 2 < ((Hp + th - 1) // th) * th:
         return False
     if len(Qs) > 1 and Qs[0].C % 64:
         return False

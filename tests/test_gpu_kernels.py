@@ -418,7 +418,7 @@ def test_bf16_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
     else:
         node = _mk_node(eng, z, "relu", scale, shift)
         srcs = [node.src()]
-    assert eng._bf16_launch(srcs, wp, H, W, H, W, 3, 3, 1, 1, eng.EPI_PLAIN, eng.MORDER_LINEAR)
+    assert eng._bf16_launch(srcs, wp, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, eng.EPI_PLAIN, eng.MORDER_LINEAR) == "halo"
     eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
     got = nchw(out.cpu())
     assert rel_err(got, ref) < 5e-4
@@ -437,21 +437,83 @@ def test_bf16_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
     assert rel_err(d1.cpu(), refn[..., c0:]) < 1e-4
 
 
-def test_bf16_rejected_for_other_shapes(eng):
-    """bf16 inputs exist for the 3x3 stride-1 kernel only: the C ABI refuses anything else instead of silently
-    computing in another precision (the engine never asks for it: it keeps such layers in fp32)."""
+def test_bf16_rejected_for_generic_shapes(eng):
+    """bf16 inputs exist for the halo and the gather kernel; a launch that needs the fully general kernel (here: a
+    concat boundary that is no multiple of 32 channels) is refused by the C ABI instead of silently computing in another
+    precision (the engine never asks for it: it keeps such layers in fp32)."""
     from microbeseg_amd import _lib
     g = torch.Generator().manual_seed(5)
-    x = rnd(g, 1, 16, 16, 32).cuda()
+    x0, x1 = rnd(g, 1, 16, 16, 16).cuda(), rnd(g, 1, 16, 16, 16).cuda()
     w = eng.pack_weight(rnd(g, 32, 32, 3, 3).cuda(), 9, 32, 32, 1, 32 * 9, 9)
-    out = torch.empty((1, 8, 8, 32), device="cuda")
+    out = torch.empty((1, 16, 16, 32), device="cuda")
+    srcs = [eng.plain_src(x0, 16), eng.plain_src(x1, 16)]
+    assert eng._bf16_launch(srcs, w, 1, 16, 16, 16, 16, 3, 3, 1, 1, eng.MODE_CONV, eng.EPI_PLAIN, eng.MORDER_LINEAR) is None
     p = _lib.MsegIgemm()
-    p.src[0] = eng.plain_src(x, 32)
-    p.nsrc, p.Cin, p.Kpad, p.Npad, p.w = 1, 32, w.Kpad, w.Npad, w.bf16().data_ptr()
+    p.src[0], p.src[1] = srcs
+    p.nsrc, p.Cin, p.Kpad, p.Npad, p.w = 2, 32, w.Kpad, w.Npad, w.bf16().data_ptr()
     p.dst0 = out.data_ptr()
-    p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad = 1, 16, 16, 8, 8, 3, 3, 2, 1
+    p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad = 1, 16, 16, 16, 16, 3, 3, 1, 1
     p.Ngemm, p.split, p.ld0, p.precision = 32, 32, 32, 1
     assert _lib.load().mseg_igemm(C.byref(p), torch.cuda.current_stream().cuda_stream) == -1
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 128, 16, 16), (1, 128, 72, 24, 40), (4, 32, 64, 32, 32)])
+def test_bf16_gather_stride2_forward_and_dgrad(eng, N, Cin, Cout, H, W):
+    """MSEG_PREC_BF16 on the gather kernel: Conv2d 3x3 stride 2 (ConvPool) forward with a norm-on-load source and its data
+    gradient in parity M-order, against torch fp32 on the bf16-rounded operands."""
+    g = torch.Generator().manual_seed(700 + Cin)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1.0, rnd(g, Cin) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    xin = _transform_cpu(z, "relu", scale, shift, False)
+    ref = F.conv2d(_bf(xin), _bf(w), b, stride=2, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    node = _mk_node(eng, z, "relu", scale, shift)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    assert eng._bf16_launch([node.src()], wp, N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, eng.EPI_PLAIN,
+                            eng.MORDER_LINEAR) == "fast"
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+    assert rel_err(nchw(out.cpu()), ref) < 5e-4
+    assert rel_err(nchw(out.cpu()), F.conv2d(xin, w, b, stride=2, padding=1)) > 1e-4
+    gy = rnd(g, N, Cout, Ho, Wo)
+    refd = F.conv_transpose2d(_bf(gy), _bf(w), None, stride=2, padding=1, output_padding=1)
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    dz = nhwc(gy).cuda()
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, Ho, Wo, H, W, 3, 3, 2, 1, eng.MODE_TCONV, Cin, dx, Cin,
+              morder=eng.MORDER_PARITY, precision="bf16")
+    # parity classes that are no whole 128-row tiles need the general kernel: the engine keeps that launch in fp32
+    kind = eng._bf16_launch([eng.plain_src(dz, Cout)], wd, N, Ho, Wo, H, W, 3, 3, 2, 1, eng.MODE_TCONV, eng.EPI_PLAIN,
+                            eng.MORDER_PARITY)
+    assert kind == ("fast" if (N * H * W) % 512 == 0 else None)
+    if kind is None:
+        refd = F.conv_transpose2d(gy, w, None, stride=2, padding=1, output_padding=1)
+    assert rel_err(nchw(dx.cpu()), refd) < 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 128, 64, 8, 8), (1, 256, 128, 8, 12)])
+def test_bf16_gather_conv_transpose(eng, N, Cin, Cout, H, W):
+    """MSEG_PREC_BF16 ConvTranspose2d 2x2 stride 2 as a 1x1 GEMM with the scatter epilogue, and its data gradient."""
+    g = torch.Generator().manual_seed(800 + Cin)
+    x = rnd(g, N, Cin, H, W)
+    w, b = rnd(g, Cin, Cout, 2, 2) * 0.1, rnd(g, Cout)
+    ref = F.conv_transpose2d(_bf(x), _bf(w), b, stride=2)
+    node = _mk_node(eng, x)
+    wp = eng.pack_weight(w.cuda(), 4, Cout, Cin, 1, 4, Cout * 4, merge_taps=True)
+    out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, out, Cout,
+              epi=eng.EPI_SCATTER2X2, Cq=Cout, precision="bf16")
+    assert rel_err(nchw(out.cpu()), ref) < 1e-4
+    assert rel_err(nchw(out.cpu()), F.conv_transpose2d(x, w, b, stride=2)) > 1e-4
+    gy = rnd(g, N, Cout, 2 * H, 2 * W)
+    refd = F.conv2d(_bf(gy), _bf(w), None, stride=2)
+    wd = eng.pack_weight(w.cuda(), 4, Cin, Cout, 1, Cout * 4, 4)
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    dz = nhwc(gy).cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, 2 * H, 2 * W, H, W, 2, 2, 2, 0, eng.MODE_CONV, Cin, dx, Cin,
+              precision="bf16")
+    assert rel_err(nchw(dx.cpu()), refd) < 1e-4
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,two_src,act", [(2, 64, 64, 16, 16, False, "relu"), (3, 72, 40, 16, 12, False, "relu"),
