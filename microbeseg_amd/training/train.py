@@ -101,10 +101,22 @@ class TrainWorker(QObject):
     stop_training = False
     is_training = False
     num_workers = None      # None -> reference rule (0 on CPU, min(cpu_count // 2, 16) otherwise)
+    precision = "fp32"      # "bf16": bf16 matrix-core inputs, fp32 accumulate / storage / statistics (BASELINE configs[2])
 
     def start_training(self, path_data, path_models, label_type, iterations, optimizer, batch_size, device, num_gpus,
                        print_output=False, filters=None, max_epochs=None):
         """ Train ``iterations`` models on ``path_data/{train,val}`` and store them in ``path_models``. """
+        from .. import engine
+        previous = engine.get_precision()
+        engine.set_precision(self.precision)
+        try:
+            return self._start_training(path_data, path_models, label_type, iterations, optimizer, batch_size, device,
+                                        num_gpus, print_output, filters, max_epochs)
+        finally:
+            engine.set_precision(previous)
+
+    def _start_training(self, path_data, path_models, label_type, iterations, optimizer, batch_size, device, num_gpus,
+                        print_output=False, filters=None, max_epochs=None):
         if len(list(path_data.glob('*'))) == 0 or len(list((path_data / 'train').glob('mask*'))) < 2 \
                 or len(list((path_data / 'val').glob('mask*'))) < 2:
             self.progress.emit(0)
@@ -139,6 +151,8 @@ class TrainWorker(QObject):
                                      'num_gpus': num_gpus,
                                      'optimizer': optimizer,
                                      'run_name': run_name}
+                    if self.precision != 'fp32':          # additive key; the reference's .json has none (fp32 only)
+                        train_configs['precision'] = self.precision
 
                     def make_net():
                         return build_unet(unet_type=train_configs['architecture'][0],

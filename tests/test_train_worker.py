@@ -147,3 +147,37 @@ def test_train_worker_on_gpu_configs0(tmp_path, label_type, optimizer):
         fmin, fmax = np.min(f), np.max(f)
         fp, pads = zero_pad_model_input(f, pad_val=fmin)
         assert np.array_equal(masks[t], iw.inference(fp, fmin, fmax, pads))
+
+
+@pytest.mark.gpu
+def test_train_worker_bf16_precision(tmp_path):
+    """BASELINE configs[2] through the worker: ``worker.precision = 'bf16'`` trains with bf16 matrix-core inputs (fp32
+    accumulate / storage / statistics), records it in the run's .json, restores the engine's mode afterwards, and the
+    training loss falls like the fp32 run's on the same data and seed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd import engine
+    from microbeseg_amd.training.train import TrainWorker
+    from microbeseg_amd.utils import synth
+    data = synth.write_training_set(tmp_path / "set", 16, 4, size=128, seed=77)
+    losses = {}
+    for prec in ("fp32", "bf16"):
+        models = tmp_path / f"models_{prec}"
+        models.mkdir()
+        torch.manual_seed(3)
+        np.random.seed(3)
+        import random
+        random.seed(3)
+        w = TrainWorker()
+        w.num_workers = 0
+        w.augment = False
+        w.precision = prec
+        w.start_training(data, models, "distance", 1, "adam", 4, torch.device("cuda:0"), 1, False, filters=[64, 128],
+                         max_epochs=6)
+        assert engine.get_precision() == "fp32"
+        cfg = json.load(open(models / "distance_model_01.json"))
+        assert cfg.get("precision", "fp32") == prec
+        log = np.loadtxt(models / "distance_model_01_loss.txt", ndmin=2, delimiter=",")
+        losses[prec] = log[:, 1]                                       # training loss per epoch
+    assert losses["bf16"][-1] < 0.7 * losses["bf16"][0]
+    assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.15 * losses["fp32"][-1]

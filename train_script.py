@@ -32,6 +32,8 @@ def main():
     parser.add_argument('--train_path', default=None, type=str, help='[extension] local labelled training set')
     parser.add_argument('--filters', default=None, type=int, nargs=2, help='[extension] first / max feature maps')
     parser.add_argument('--max_epochs', default=None, type=int, help='[extension] epoch budget override')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                        help='[extension] bf16 = bf16 matrix-core inputs, fp32 accumulate / storage / statistics')
     args = parser.parse_args()
 
     if args.method not in ('boundary', 'distance'):
@@ -61,6 +63,7 @@ def main():
 
     from microbeseg_amd.training.train import TrainWorker
     worker = TrainWorker()
+    worker.precision = args.precision
     worker.start_training(path_data, model_path, args.method, args.iterations, args.optimizer.lower(), args.batch_size,
                           device, world, True, filters=args.filters, max_epochs=args.max_epochs)
     if world > 1:
