@@ -923,8 +923,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define HB_STRIDE 40          // bf16 elements per LDS row
 
 template <int BN, int TR>
-__global__ __launch_bounds__(512, 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
-                                                                 int chunks_per_split) {
+__global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                 int chunks_per_split, int m_fastest) {
   constexpr int BM = 128;
   using Cfg = HaloCfg<BN>;
   constexpr int HMAX = 204;                          // (4 + 2) x (32 + 2), the largest halo (tw_log2 <= 5)
@@ -950,7 +950,13 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_bf16_kernel(const MsegIgemm
   const int ntiles_all = (int)gridDim.x / ksplit;
   const int kz = lid_all / ntiles_all;
   const int lid = lid_all - kz * ntiles_all;
-  const int tile_m = lid / ntiles_n, tile_n = lid - tile_m * ntiles_n;
+  // Workgroup order inside an XCD (neighbouring logical ids share an L2).  N tiles fastest: the N tiles of a pixel tile
+  // run together and share its halo.  With many input channels the WEIGHTS are the larger stream (9 x Cin x BN bf16 per
+  // tile, all of it re-read by every pixel tile): pixel tiles fastest then keeps ONE column of weight tiles (<= 2.4 MB)
+  // resident in each XCD's 4 MB L2 instead of cycling the whole weight tensor through it.
+  const int ntiles_m = ntiles_all / ntiles_n;
+  const int tile_m = m_fastest ? lid % ntiles_m : lid / ntiles_n;
+  const int tile_n = m_fastest ? lid / ntiles_m : lid - tile_m * ntiles_n;
   const int img = tile_m / (tiles_x * tiles_y);
   const int trem = tile_m - img * (tiles_x * tiles_y);
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -1478,8 +1484,10 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     }
     const dim3 hgrid((unsigned)(htiles * ks));
 #define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
+    // weight tensor beyond ~2 MB (bf16) and several N tiles: pixel tiles fastest (see the kernel)
+    const int m_fastest = ((long long)9 * p.Kpad * p.Ngemm * 2 > (2ll << 20)) && (p.Ngemm > BNv) ? 1 : 0;
 #define MSEG_HALO16(BN_, TR_) \
-  hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
+  hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest)
     if (p.precision == MSEG_PREC_BF16) {
       if (wide) { if (tr == 0) MSEG_HALO16(128, 0); else if (tr == 1) MSEG_HALO16(128, 1); else MSEG_HALO16(128, 2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }

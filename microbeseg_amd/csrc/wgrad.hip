@@ -711,21 +711,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   const int srem0 = step_begin - sn * steps_img;
   int spy = (srem0 / bx) * TH, spx0 = (srem0 - (srem0 / bx) * bx) * TW;
   // per-thread constants: P rows k = spx + 16 i (block pixel (k / TW, k % TW)), Q halo rows s = spx + 16 i
-  int pr[NP];
-  unsigned pv[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int k = spx + 16 * i;
-    pr[i] = k >> TWL;
-    pv[i] = (unsigned)(pr[i] * p.Wp + (k & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
-  }
-  int qr[NQ], qj[NQ];
-  unsigned qv[NQ];
+  // (block row of P row k = spx + 16 i: (spx >> TWL) + (16 >> TWL) * i — derived, not stored)
+  // P row k = spx + 16 i is block pixel ((spx >> TWL) + (16 >> TWL) i, spx % TW): one per-lane offset, the step between
+  // the rows of a thread is wave-uniform.  Address constants are kept few on purpose: the 144 accumulators + 44 staging
+  // registers leave no room, and a spilled constant is reloaded in every step.
+  const int pr0 = spx >> TWL;
+  const unsigned pv0 = (unsigned)(pr0 * p.Wp + (spx & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
+  const unsigned pvstep = (unsigned)((16 >> TWL) * p.Wp) * mC4;                  // scalar
+  int qrj[NQ];                                         // halo row << 8 | halo column
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int sidx = spx + 16 * i;
-    qr[i] = sidx / QW; qj[i] = sidx - qr[i] * QW;
-    qv[i] = (unsigned)(qr[i] * p.Wq + qj[i]) * qC4 + qcl4;
+    const int r = sidx / QW, c = sidx - r * QW;
+    qrj[i] = (r << 8) | c;
   }
   // LDS element offsets of this thread's staging writes: plane (sc4 >> 3), row, 4 channels at (sc4 & 7) * 4
   const int wplane = sc4 >> 3, wcol = (sc4 & 7) * 4;
@@ -736,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   const int b_lane = PEL + (wn * QROWS + (TWL == 3 ? lh * QW : 2 * lh * QW) + tq) * 32 + tcb * 16 + tp * 4;
 
   float4 rp[NP], rq[NQ];
-  float qm[NQ];
+  unsigned qmask = 0u;                                 // bit i: halo row i of the step in flight is a real pixel
   const bool q_ps = QTR && qs.scale && qs.ss != 0;
   int tab_n = -1;
 
@@ -757,21 +755,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const bool pok = live & mvalid & (spy + pr[i] < p.Hp);
-      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv[i] : OOB, psoff, 0));
+      const bool pok = live & mvalid & (spy + pr0 + (16 >> TWL) * i < p.Hp);
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv0 + pvstep * i : OOB,
+                                                                                       psoff, 0));
       rp[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
     const int qy0 = spy - p.pad, qx0 = spx0 - p.pad;
-    const unsigned sb = (unsigned)(qy0 * p.Wq + qx0) * qC4;                      // wraps by design (halo rows < 0)
+    unsigned okbits = 0u;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const bool qlive = spx + 16 * i < QROWS;
-      const int qy = qy0 + qr[i], qx = qx0 + qj[i];
+      const int qy = qy0 + (qrj[i] >> 8), qx = qx0 + (qrj[i] & 255);
       const bool ok = live & qvalid & qlive & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
-      const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? sb + qv[i] : OOB, 0, 0));
+      const unsigned qo = (unsigned)(qy * p.Wq + qx) * qC4 + qcl4;
+      const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? qo : OOB, 0, 0));
       rq[i] = make_float4(q[0], q[1], q[2], q[3]);
-      if (QTR) qm[i] = ok ? 1.f : 0.f;
+      okbits |= (unsigned)ok << i;
     }
+    qmask = okbits;
     spx0 += TW;
     if (spx0 >= p.Wp) { spx0 = 0; spy += TH; if (spy >= p.Hp) { spy = 0; sn += 1; } }
   };
@@ -793,8 +794,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
         if (QTR != 0) {
           if (QTR == 2) v = act_fwd4(v, qs.act);
           else { v.x = clamp_lo(v.x, qlo); v.y = clamp_lo(v.y, qlo); v.z = clamp_lo(v.z, qlo); v.w = clamp_lo(v.w, qlo); }
-          v.x = (v.x * qsc.x + qsh.x) * qm[i]; v.y = (v.y * qsc.y + qsh.y) * qm[i];
-          v.z = (v.z * qsc.z + qsh.z) * qm[i]; v.w = (v.w * qsc.w + qsh.w) * qm[i];
+          const float m = ((qmask >> i) & 1u) ? 1.f : 0.f;
+          v.x = (v.x * qsc.x + qsh.x) * m; v.y = (v.y * qsc.y + qsh.y) * m;
+          v.z = (v.z * qsc.z + qsh.z) * m; v.w = (v.w * qsc.w + qsh.w) * m;
         }
         *reinterpret_cast<wbf16x4*>(stage + PEL + (wplane * QROWS + spx + 16 * i) * 32 + wcol) = to_bf(v);
       }
@@ -960,8 +962,9 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   }
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   const int per_split_wgs = sel.kind == 3 ? tiles : tiles * p.KH;
-  // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs
-  long long s = p.splits > 0 ? p.splits : (768 + per_split_wgs - 1) / per_split_wgs;
+  // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs (bf16 kernel: 2 resident -> 512)
+  const int round_wgs = sel.kind == 3 ? 512 : 768;
+  long long s = p.splits > 0 ? p.splits : (round_wgs + per_split_wgs - 1) / per_split_wgs;
   if (s > steps_total) s = steps_total;
   if (s > 2048) s = 2048;
   if (s < 1) s = 1;
