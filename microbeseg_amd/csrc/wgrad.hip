@@ -652,12 +652,18 @@ __device__ __forceinline__ wbf16x8 wb_tr_read8(const __bf16* lo, const __bf16* h
   return __builtin_bit_cast(wbf16x8, v);
 }
 
-template <int TWL, int QTR>
+// The same kernel covers the strided layers (S = 2): KT = 3 is the weight gradient of a 3x3 stride-2 convolution (ConvPool;
+// Q = its input, twice the size of P = dz), KT = 2 that of ConvTranspose2d 2x2 stride 2 (P = its input, with norm-on-load
+// transform PTR; Q = the gradient of its output).  The Q image of a block is (S TH + KT - S) x (S TW + KT - S) pixels, a tap
+// is still a row offset and consecutive block pixels are S image rows apart — every lane of a transposed read supplies
+// its own row address, so the stride costs nothing.  Blocks are 32 pixels for S = 2 (the Q image is four times the block).
+template <int TWL, int QTR, int S = 1, int KT = 3, int PTR = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad p, int splits, int steps_per_split) {
-  constexpr int TW = 1 << TWL, TH = WB_PIX >> TWL, QW = TW + 2, QH = TH + 2;
-  constexpr int QROWS = QH * QW;                       // 100 (8 x 8 blocks) or 108 (16 x 4)
-  constexpr int NP = WB_PIX / 16, NQ = (QROWS + 15) / 16;
-  constexpr int PEL = 2 * WB_PIX * 32, QEL = 2 * QROWS * 32;
+  constexpr int PIX = S == 1 ? WB_PIX : 32, NT = KT * KT;
+  constexpr int TW = 1 << TWL, TH = PIX >> TWL, QW = S * TW + KT - S, QH = S * TH + KT - S;
+  constexpr int QROWS = QH * QW;                       // S = 1: 100 (8 x 8 blocks) or 108 (16 x 4); S = 2: 153 or 128
+  constexpr int NP = PIX / 16, NQ = (QROWS + 15) / 16;
+  constexpr int PEL = 2 * PIX * 32, QEL = 2 * QROWS * 32;
   constexpr int STAGE = PEL + QEL;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
 
@@ -680,9 +686,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   if (step_end > steps_total) step_end = steps_total;
   const int nsteps = step_end > step_begin ? step_end - step_begin : 0;
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -695,11 +701,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
   const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
   const unsigned OOB = 0x80000000u;
-  const int HWp = p.Hp * p.Wp;
+  const int HWp = p.Hp * p.Wp, HWq = p.Hq * p.Wq;
   __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * 4, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWp * qs.C * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWq * qs.C * 4, 0x00020000);
   int desc_n = 0;
-  float4 qsc, qsh;
+  float4 qsc, qsh, psc, psh;
+  if (PTR) {
+    const float* a = p.P.scale ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
+    const float* b = p.P.scale ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
+    psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
+  }
+  const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
   {
     const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
     const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
@@ -730,37 +742,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   // transposed-read addresses: lane 4q + pp of a 16-lane group supplies row q, channels 4 pp .. 4 pp + 3 of its block;
   // the group (lane >> 4) & 1 takes channels 16 .. 31 of the wave's 32, the half lane >> 5 the pixels 8 .. 15 of a k-step
   const int tq = (lane >> 2) & 3, tp = lane & 3, tcb = (lane >> 4) & 1;
-  const int a_lane = (wm * WB_PIX + 8 * lh + tq) * 32 + tcb * 16 + tp * 4;
-  const int b_lane = PEL + (wn * QROWS + (TWL == 3 ? lh * QW : 2 * lh * QW) + tq) * 32 + tcb * 16 + tp * 4;
+  const int a_lane = (wm * PIX + 8 * lh + tq) * 32 + tcb * 16 + tp * 4;
+  const int b_lane = PEL + (wn * QROWS + (TWL == 3 ? S * lh * QW : 2 * S * lh * QW) + S * tq) * 32 + tcb * 16 + tp * 4;
 
   float4 rp[NP], rq[NQ];
   unsigned qmask = 0u;                                 // bit i: halo row i of the step in flight is a real pixel
+  unsigned pmask = 0u;                                 // same for the P rows (PTR only)
   const bool q_ps = QTR && qs.scale && qs.ss != 0;
+  const bool p_ps = PTR && p.P.scale && p.P.ss != 0;
   int tab_n = -1;
 
   auto issue = [&](int step) {
     const bool live = step < nsteps;
-    if (q_ps && live && sn != tab_n) {
+    if ((q_ps || p_ps) && live && sn != tab_n) {
       tab_n = sn;
-      qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
-      qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      if (q_ps) {
+        qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+        qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      }
+      if (p_ps) {
+        psc = *reinterpret_cast<const float4*>(p.P.scale + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+        psh = *reinterpret_cast<const float4*>(p.P.shift + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+      }
     }
     if (live && sn != desc_n) {
       desc_n = sn;
       rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr + (size_t)sn * HWp * Mch), 0, HWp * Mch * 4,
                                               0x00020000);
-      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWp * qs.C), 0, HWp * qs.C * 4,
+      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWq * qs.C), 0, HWq * qs.C * 4,
                                               0x00020000);
     }
     const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;
+    unsigned pbits = 0u;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const bool pok = live & mvalid & (spy + pr0 + (16 >> TWL) * i < p.Hp);
       const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv0 + pvstep * i : OOB,
                                                                                        psoff, 0));
       rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+      pbits |= (unsigned)pok << i;
     }
-    const int qy0 = spy - p.pad, qx0 = spx0 - p.pad;
+    pmask = pbits;
+    const int qy0 = S * spy - p.pad, qx0 = S * spx0 - p.pad;
     unsigned okbits = 0u;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -785,8 +808,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
 
   auto commit = [&](__bf16* stage) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      *reinterpret_cast<wbf16x4*>(stage + (wplane * WB_PIX + spx + 16 * i) * 32 + wcol) = to_bf(rp[i]);
+    for (int i = 0; i < NP; ++i) {
+      float4 v = rp[i];
+      if (PTR != 0) {
+        if (PTR == 2) v = act_fwd4(v, p.P.act);
+        else { v.x = clamp_lo(v.x, plo); v.y = clamp_lo(v.y, plo); v.z = clamp_lo(v.z, plo); v.w = clamp_lo(v.w, plo); }
+        const float m = ((pmask >> i) & 1u) ? 1.f : 0.f;
+        v.x = (v.x * psc.x + psh.x) * m; v.y = (v.y * psc.y + psh.y) * m;
+        v.z = (v.z * psc.z + psh.z) * m; v.w = (v.w * psc.w + psh.w) * m;
+      }
+      *reinterpret_cast<wbf16x4*>(stage + (wplane * PIX + spx + 16 * i) * 32 + wcol) = to_bf(v);
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       if (spx + 16 * i < QROWS) {
@@ -815,18 +847,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     const __bf16* ap = st + a_lane;
     const __bf16* bp = st + b_lane;
 #pragma unroll
-    for (int s4 = 0; s4 < WB_PIX / 16; ++s4) {
+    for (int s4 = 0; s4 < PIX / 16; ++s4) {
       // pixels k0 = 16 s4 + 8 lh (+4): P rows are the block pixels in order
       const wbf16x8 a = wb_tr_read8(ap + (16 * s4) * 32, ap + (16 * s4 + 4) * 32);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < KT; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          // halo row of pixel k0 for tap (ky, kx): ((k0 / TW) + ky) * QW + k0 % TW + kx; the lane part is in b_lane
-          const int r0 = TWL == 3 ? (2 * s4 + ky) * QW + kx : (4 * s4 + ky) * QW + kx;
-          const int r1 = TWL == 3 ? r0 + 4 : r0 + QW;
+        for (int kx = 0; kx < KT; ++kx) {
+          // Q image row of pixel k0 for tap (ky, kx): (S (k0 / TW) + ky) * QW + S (k0 % TW) + kx; the lane part is in b_lane
+          const int r0 = TWL == 3 ? (2 * S * s4 + ky) * QW + kx : (4 * S * s4 + ky) * QW + kx;
+          const int r1 = TWL == 3 ? r0 + 4 * S : r0 + S * QW;
           const wbf16x8 b = wb_tr_read8(bp + r0 * 32, bp + r1 * 32);
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ky * 3 + kx], 0, 0, 0);
+          acc[ky * KT + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ky * KT + kx], 0, 0, 0);
         }
     }
     commit(lds + (buf ^ 1) * STAGE);
@@ -837,11 +869,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   const int n = nt * 64 + wn * 32 + li;
   if (n < Nch) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < Mch) p.ws[(((size_t)split * 9 + t) * Mch + m) * Nch + n] = acc[t][r];
+        if (m < Mch) p.ws[(((size_t)split * NT + t) * Mch + m) * Nch + n] = acc[t][r];
       }
     }
   }
@@ -937,6 +969,14 @@ static WgradSel wgrad_select(const MsegWgrad& p) {
                       (p.Wp % 4) == 0 && w.ptr == 0 && image_fits && pix_ok && concat_ok &&
                       (long long)p.Hp * 2 >= (long long)((p.Hp + TH - 1) / TH) * TH;     // >= 50 % of the block rows
     w.kind = ok16 ? 3 : -1;                            // -1: the launch is refused (the engine keeps such layers fp32)
+    if (!ok16 && p.stride == 2 && p.Hq == 2 * p.Hp && p.Wq == 2 * p.Wp && (p.Wp % 4) == 0 && image_fits && pix_ok &&
+        p.nq == 1) {
+      // strided layers: 32-pixel blocks, 4 x 8 or 8 x 4
+      const int TH2 = 32 >> w.tw_log2;
+      const bool rows_ok = (long long)p.Hp * 2 >= (long long)((p.Hp + TH2 - 1) / TH2) * TH2;
+      if (rows_ok && p.KH == 3 && p.KW == 3 && p.pad == 1 && w.ptr == 0) w.kind = 4;        // 3x3 stride-2 conv
+      if (rows_ok && p.KH == 2 && p.KW == 2 && p.pad == 0 && w.qtr == 0) w.kind = 5;        // ConvTranspose 2x2
+    }
     return w;
   }
   halo = halo && image_fits && pix_ok && concat_ok;
@@ -956,14 +996,14 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
     const int TH = WG_PIX >> sel.tw_log2;
     steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks (wgrad_halo_kernel)
   }
-  if (sel.kind == 3) {
-    const int TH = 64 >> sel.tw_log2;
-    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // 64-pixel blocks, all 9 taps
+  if (sel.kind >= 3) {
+    const int TH = (sel.kind == 3 ? 64 : 32) >> sel.tw_log2;
+    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks, all taps per workgroup
   }
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
-  const int per_split_wgs = sel.kind == 3 ? tiles : tiles * p.KH;
+  const int per_split_wgs = sel.kind >= 3 ? tiles : tiles * p.KH;
   // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs (bf16 kernel: 2 resident -> 512)
-  const int round_wgs = sel.kind == 3 ? 512 : 768;
+  const int round_wgs = sel.kind >= 3 ? 512 : 768;
   long long s = p.splits > 0 ? p.splits : (round_wgs + per_split_wgs - 1) / per_split_wgs;
   if (s > steps_total) s = steps_total;
   if (s > 2048) s = 2048;
@@ -1008,7 +1048,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     const WgradSel sel = wgrad_select(p);
     const bool generic = sel.generic_act, per_sample = sel.per_sample;
     const int ptr = sel.ptr, qtr = sel.qtr, tw_log2 = sel.tw_log2;
-    const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)(sel.kind == 3 ? 1 : p.KH)), block(256);
+    const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)(sel.kind >= 3 ? 1 : p.KH)), block(256);
     if (sel.kind != 0) {
       static bool ident_ready[64] = {false};
       int devid = 0;
@@ -1018,7 +1058,23 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
         MSEG_LAUNCH_CHECK();
         ident_ready[devid] = true;
       }
-      if (sel.kind == 3) {
+      if (sel.kind == 4) {                             // 3x3 stride-2 convolution (plain P)
+#define MSEG_WB4(T_, Q_) \
+  hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB4_Q(T_) do { if (qtr == 0) MSEG_WB4(T_, 0); else if (qtr == 1) MSEG_WB4(T_, 1); else MSEG_WB4(T_, 2); } while (0)
+        if (tw_log2 == 3) MSEG_WB4_Q(3); else MSEG_WB4_Q(2);
+#undef MSEG_WB4_Q
+#undef MSEG_WB4
+        MSEG_LAUNCH_CHECK();
+      } else if (sel.kind == 5) {                      // ConvTranspose2d 2x2 stride 2 (plain Q)
+#define MSEG_WB5(T_, P_) \
+  hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB5_P(T_) do { if (ptr == 0) MSEG_WB5(T_, 0); else if (ptr == 1) MSEG_WB5(T_, 1); else MSEG_WB5(T_, 2); } while (0)
+        if (tw_log2 == 3) MSEG_WB5_P(3); else MSEG_WB5_P(2);
+#undef MSEG_WB5_P
+#undef MSEG_WB5
+        MSEG_LAUNCH_CHECK();
+      } else if (sel.kind == 3) {
 #define MSEG_WB(T_, Q_) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_WB_Q(T_) do { if (qtr == 0) MSEG_WB(T_, 0); else if (qtr == 1) MSEG_WB(T_, 1); else MSEG_WB(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB_Q(3); else MSEG_WB_Q(2);

@@ -312,23 +312,34 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
 
 
 def _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad):
-    """does this weight gradient take the bf16 kernel in bf16 mode?  (mirror of wgrad_select in csrc/wgrad.hip)"""
-    if not (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Hq == Hp and Wq == Wp and Wp % 4 == 0 and _tr_of(P) == 0):
-        return False
-    th = 8 if Wp % 8 == 0 else 16
-    if Hp * 2 < ((Hp + th - 1) // th) * th:
-        return False
-    if len(Qs) > 1 and Qs[0].C % 64:
-        return False
-    if NB * Hp * Wp + 2048 * 32 >= 2 ** 31 - 1:
-        return False
-    return Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
+    """does this weight gradient take a bf16 kernel in bf16 mode?  (mirror of wgrad_select in csrc/wgrad.hip)
+    Returns the kernel's name in a rocprofv3 trace, or None = the launch stays fp32."""
+    if Wp % 4 or NB * Hp * Wp + 2048 * 32 >= 2 ** 31 - 1:
+        return None
+    if not (Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)):
+        return None
+    twl = 3 if Wp % 8 == 0 else 2
+    qtr = max(_tr_of(s) for s in Qs)
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Hq == Hp and Wq == Wp and _tr_of(P) == 0:
+        th = 64 >> twl
+        if Hp * 2 < ((Hp + th - 1) // th) * th or (len(Qs) > 1 and Qs[0].C % 64):
+            return None
+        return "wgrad_halo_bf16_kernel<%d, %d, 1, 3, 0>" % (twl, qtr)
+    if stride == 2 and Hq == 2 * Hp and Wq == 2 * Wp and len(Qs) == 1:
+        th = 32 >> twl
+        if Hp * 2 < ((Hp + th - 1) // th) * th:
+            return None
+        if KH == 3 and KW == 3 and pad == 1 and _tr_of(P) == 0:
+            return "wgrad_halo_bf16_kernel<%d, %d, 2, 3, 0>" % (twl, qtr)
+        if KH == 2 and KW == 2 and pad == 0 and qtr == 0:
+            return "wgrad_halo_bf16_kernel<%d, 0, 2, 2, %d>" % (twl, _tr_of(P))
+    return None
 
 
 def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None, precision=None):
     lib = _lib.load()
     p = MsegWgrad()
-    bf16 = (precision or _precision) == "bf16" and _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad)
+    bf16 = _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad) if (precision or _precision) == "bf16" else None
     p.precision = 1 if bf16 else 0
     p.P = P
     for i, s in enumerate(Qs):
@@ -350,7 +361,7 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
     name = _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride)
     if bf16:
-        name = "wgrad_halo_bf16_kernel<%d, %d>" % (3 if Wp % 8 == 0 else 2, max(_tr_of(s) for s in Qs))
+        name = bf16
     e0, e1 = _timer.bracket(name, flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()

@@ -548,3 +548,35 @@ def test_bf16_halo_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
     eng.wgrad(P, qs, dW, N, H, W, H, W, 3, 3, 1, 1, ws, precision="bf16")
     assert rel_err(dW.cpu(), ref) < 5e-4
     assert 1e-5 < rel_err(dW.cpu(), exact) < 2e-2
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 128, 16, 16), (1, 128, 72, 24, 40), (3, 32, 64, 32, 24)])
+def test_bf16_strided_wgrads(eng, N, Cin, Cout, H, W):
+    """MSEG_PREC_BF16 weight gradients of the strided layers through the same transposed-read kernel: Conv2d 3x3 stride 2
+    (ConvPool; norm-on-load input) and ConvTranspose2d 2x2 stride 2 (norm-on-load input as the P operand)."""
+    g = torch.Generator().manual_seed(900 + Cin)
+    z = rnd(g, N, Cin, H, W)
+    scale, shift = rnd(g, Cin) * 0.3 + 1, rnd(g, Cin) * 0.1
+    xin = _transform_cpu(z, "relu", scale, shift, False)
+    node = _mk_node(eng, z, "relu", scale, shift, False)
+    ws = eng.Workspace(torch.device("cuda"))
+    # stride-2 conv: P = dz (H/2 x W/2), Q = input
+    Ho, Wo = H // 2, W // 2
+    gy = rnd(g, N, Cout, Ho, Wo)
+    ref = torch.nn.grad.conv2d_weight(_bf(xin), (Cout, Cin, 3, 3), _bf(gy), stride=2, padding=1)
+    dz = nhwc(gy).cuda()
+    P = eng.plain_src(dz, Cout)
+    assert eng._wgrad_bf16_ok(P, [node.src()], N, Ho, Wo, H, W, 3, 3, 2, 1)
+    dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    eng.wgrad(P, [node.src()], dW, N, Ho, Wo, H, W, 3, 3, 2, 1, ws, precision="bf16")
+    assert rel_err(dW.cpu(), ref) < 5e-4
+    assert rel_err(dW.cpu(), torch.nn.grad.conv2d_weight(xin, (Cout, Cin, 3, 3), gy, stride=2, padding=1)) > 1e-5
+    # ConvTranspose2d(Cin, Cout, 2, 2): P = its (normalised) input, Q = gradient of its output (2H x 2W)
+    gy2 = rnd(g, N, Cout, 2 * H, 2 * W)
+    refT = torch.nn.grad.conv2d_weight(_bf(gy2), (Cin, Cout, 2, 2), _bf(xin), stride=2)
+    dz2 = nhwc(gy2).cuda()
+    Q = eng.plain_src(dz2, Cout)
+    assert eng._wgrad_bf16_ok(node.src(), [Q], N, H, W, 2 * H, 2 * W, 2, 2, 2, 0)
+    dWT = torch.full((Cin, Cout, 2, 2), float("nan"), device="cuda")
+    eng.wgrad(node.src(), [Q], dWT, N, H, W, 2 * H, 2 * W, 2, 2, 2, 0, ws, precision="bf16")
+    assert rel_err(dWT.cpu(), refT) < 5e-4

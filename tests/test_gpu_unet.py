@@ -179,18 +179,19 @@ def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch
 
 def _bf16_rule(kind, xs, ws):
     """which of (forward, data gradient, weight gradient) of a layer the engine runs with bf16 operands: mirror of
-    engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32; weight
-    gradients of the stride-2 / transposed layers: fp32 kernels)"""
+    engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32)"""
     N, cin, H, W = xs
-    if kind == "up":
-        return (True, True, False)
-    if kind == "pool":
-        return (True, (N * H * W) % 512 == 0, False)      # stride-2 data gradient: parity classes of whole 128-row tiles
+
+    def rows_ok(h, w, pix):                               # pixel blocks of the bf16 weight-gradient kernel
+        th = pix // (8 if w % 8 == 0 else 4)
+        return w % 4 == 0 and h * 2 >= ((h + th - 1) // th) * th
+    if kind == "up":                                      # P = the layer's input (H x W)
+        return (True, True, rows_ok(H, W, 32))
+    if kind == "pool":                                    # P = dz (H/2 x W/2); data gradient: whole 128-row parity tiles
+        return (True, (N * H * W) % 512 == 0, H % 2 == 0 and W % 2 == 0 and rows_ok(H // 2, W // 2, 32))
     if cin <= 4:
         return (False, False, False)
-    th = 8 if W % 8 == 0 else 16
-    wg = W % 4 == 0 and H * 2 >= ((H + th - 1) // th) * th
-    return (True, True, wg)          # forward / data gradient: halo kernel, or the gather kernel where it does not tile
+    return (True, True, rows_ok(H, W, 64))   # forward / data gradient: halo kernel, or the gather kernel where it does not tile
 
 
 @pytest.mark.parametrize("ut,act,norm,filters,size,batch", [("DU", "elu", "bn", (64, 128), 64, 2),
