@@ -283,7 +283,10 @@ def main():
     if fwd_gflop is not None:
         train_tflop_per_crop = 3.0 * fwd_gflop * (args.size / 256.0) ** 2 / 1e3
         out["model_tflops_per_gpu"] = round(value / world * train_tflop_per_crop, 2)
-        out["frac_of_fp32_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_FP32_MFMA_TFLOPS, 4)
+        if args.precision == "fp32":
+            out["frac_of_fp32_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_FP32_MFMA_TFLOPS, 4)
+        else:
+            out["frac_of_bf16_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_BF16_MFMA_TFLOPS, 4)
     if prof is not None:
         kernels = prof.summary()
         if kernels:

@@ -4,7 +4,7 @@ import json
 import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["value"], d["unit"], d["ms_per_step"], "ms/step", d.get("frac_of_fp32_mfma_peak"))
+print(d["value"], d["unit"], d["ms_per_step"], "ms/step", d.get("frac_of_fp32_mfma_peak", d.get("frac_of_bf16_mfma_peak")))
 tot = 0.0
 for k, v in sorted(d.get("kernels", {}).items(), key=lambda kv: -kv[1]["total_ms_per_step"]):
     tot += v["total_ms_per_step"]
