@@ -195,7 +195,9 @@ def _bf16_rule(kind, xs, ws):
 
 
 @pytest.mark.parametrize("ut,act,norm,filters,size,batch", [("DU", "elu", "bn", (64, 128), 64, 2),
-                                                            ("U", "mish", "bn", (64, 128), 48, 3)])
+                                                            ("U", "mish", "bn", (64, 128), 48, 3),
+                                                            ("DU", "mish", "gn", (64, 128), 64, 2),     # per-sample tables
+                                                            ("U", "elu", "in", (64, 128), 64, 2)])
 def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev):
     """BASELINE configs[2] (bf16 forward / backward, fp32 accumulate and norm statistics): engine.set_precision('bf16')
     against the oracle with the SAME rounding points (oracle/unet_ref.py BF16_RULE: operands of the 3x3 stride-1
