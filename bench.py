@@ -171,6 +171,7 @@ def inference_metric(args, net, dev):
             "unit": "Mpx/s", "frame": f"{S}x{S}", "frames": T, "stack_ms_per_frame": round(t_stack, 2),
             "serial_Mpx_s": round(S * S / (t_net + t_pp) / 1e3, 2), "net_ms": round(t_net, 2),
             "postproc_ms": round(t_pp, 2),
+            "net_precision": args.precision,
             "postproc_Mpx_s": round(S * S / t_pp / 1e3, 1), "instances": int(n_inst), "postproc_status": int(status),
             "labels_bit_exact_vs_oracle": exact,
             "cpu_postproc": {"value": round(S * S / t_cpu / 1e6, 2), "unit": "Mpx/s", "cores": 1, "kind": "port",

@@ -40,6 +40,9 @@ def main():
     parser.add_argument('--channel', '-c', default=0, type=int, help='Channel to segment')
     parser.add_argument('--device', '-d', default='cuda:0', type=str, help='"cuda:N"')
     parser.add_argument('--overwrite', '-o', default=False, action='store_true', help='Overwrite existing results')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                        help='[extension] bf16 = bf16 matrix-core inputs for the network (faster; masks are no longer '
+                             'guaranteed identical to the fp32 reference arithmetic)')
     args = parser.parse_args()
 
     imgs_path = Path(args.img_dir)
@@ -58,6 +61,7 @@ def main():
         print('No files found')
         return
     worker = InferWorker(model=args.model, device=args.device, ths=args.thresholds, channel=args.channel)
+    worker.precision = args.precision
     worker.text_output.connect(print)
     torch.set_grad_enabled(False)
     print('--- Start inference ---')

@@ -204,6 +204,22 @@ def get_precision():
     return _precision
 
 
+class precision_scope:
+    """``with engine.precision_scope('bf16'): ...`` — set_precision for a block, restored on exit"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.previous = get_precision()
+        set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.previous)
+        return False
+
+
 # ---- thin kernel wrappers ------------------------------------------------------------------------------------
 def _round_up(v, m):
     return (v + m - 1) // m * m

@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, engine
 from ..utils.qt_shim import QObject, pyqtSignal, pyqtSlot
 from ..utils.unets import build_unet, get_weights
 from ..utils.utils import zero_pad_model_input
@@ -45,6 +45,10 @@ class InferWorker(QObject):
     progress = pyqtSignal(int)
     text_output = pyqtSignal(str)
     stop_inference = False
+    # [extension] "bf16": the network forward runs with bf16 matrix-core inputs (fp32 accumulate / storage),
+    # ~3x faster; predictions differ from the fp32 reference arithmetic in the third digit, so masks are no longer
+    # guaranteed bit-identical to the reference's — opt-in only, the default is the reference's fp32
+    precision = "fp32"
 
     def __init__(self, img_id_list=None, inference_path=None, user=None, pw=None, host=None, port=None, group_id=None,
                  model=None, device='cuda:0', ths=(0.10, 0.45), channel=0, upload=True, overwrite=True,
@@ -94,14 +98,16 @@ class InferWorker(QObject):
     def _predict(self, img_batch, pads):
         lib = _lib.load()
         if self.model_settings['label_type'] == 'distance':
-            border, cell = self.net(img_batch)
+            with engine.precision_scope(self.precision):
+                border, cell = self.net(img_batch)
             cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
             border = border[0, 0, pads[0]:, pads[1]:].contiguous()
             # every reference caller hands (H, W, 1) arrays to distance_postprocessing -> column-major instance ids
             labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1], th_cell=self.ths[0],
                                                              col_major_ids=True)
         else:
-            logits = self.net(img_batch).contiguous()
+            with engine.precision_scope(self.precision):
+                logits = self.net(img_batch).contiguous()
             _, _, hp, wp = logits.shape
             probs = torch.empty((hp - pads[0], wp - pads[1], 3), dtype=torch.float32, device=logits.device)
             _lib.check(lib.mseg_softmax3_hwc(logits.data_ptr(), hp, wp, int(pads[0]), int(pads[1]), probs.data_ptr(),
@@ -153,7 +159,8 @@ class InferWorker(QObject):
                 img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
                 try:
                     img_batch = img_batch.to(self.device)
-                    border, cell = self.net(img_batch)
+                    with engine.precision_scope(self.precision):
+                        border, cell = self.net(img_batch)
                     cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
                     border = border[0, 0, pads[0]:, pads[1]:].contiguous()
                     ready = torch.cuda.Event()

@@ -181,3 +181,37 @@ def test_train_worker_bf16_precision(tmp_path):
         losses[prec] = log[:, 1]                                       # training loss per epoch
     assert losses["bf16"][-1] < 0.7 * losses["bf16"][0]
     assert abs(losses["bf16"][-1] - losses["fp32"][-1]) < 0.15 * losses["fp32"][-1]
+
+
+@pytest.mark.gpu
+def test_infer_worker_bf16_option(tmp_path):
+    """Opt-in bf16 inference: a trained distance model segments a synthetic frame almost like the fp32 run (AJI+ of the
+    two masks >= 0.9 — not bit-identical by construction), the default stays fp32 and the engine's mode is restored."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd import engine
+    from microbeseg_amd.training.train import TrainWorker
+    from microbeseg_amd.inference.infer import InferWorker
+    from microbeseg_amd.evaluation.stats_utils import aji_plus_masks
+    from microbeseg_amd.utils import synth
+    data = synth.write_training_set(tmp_path / "set", 24, 6, size=128, seed=21)
+    models = tmp_path / "models"
+    models.mkdir()
+    torch.manual_seed(5)
+    w = TrainWorker()
+    w.num_workers = 0
+    w.augment = False
+    w.start_training(data, models, "distance", 1, "adam", 4, torch.device("cuda:0"), 1, False, filters=[64, 128],
+                     max_epochs=40)
+    rng = np.random.Generator(np.random.PCG64(99))
+    frames = np.stack([synth.synth_crop(rng, 192)["img"] for _ in range(3)])
+    iw = InferWorker(model=str(models / "distance_model_01"), device="cuda:0")
+    assert iw.precision == "fp32"
+    m32 = iw.infer_stack(frames)
+    iw.precision = "bf16"
+    m16 = iw.infer_stack(frames)
+    assert engine.get_precision() == "fp32"
+    assert m16.shape == m32.shape and m16.dtype == np.uint16
+    assert m32.max() > 3                                   # the model segments something
+    for a, b in zip(m32, m16):
+        assert aji_plus_masks(a, b) >= 0.9
