@@ -1123,6 +1123,239 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
 }
 
+// ---- 4-wave form of the bf16 halo kernel for BN = 128 --------------------------------------------------------------------
+// Same tile (128 pixels x 128 channels), LDS images and stage structure as igemm_halo_bf16_kernel, but FOUR waves that own
+// 64 x 64 each (2 x 2 MFMA blocks): a stage is 24 MFMAs per wave instead of 12 and needs one LDS read per MFMA instead of
+// 1.5; with one wave per SIMD and workgroup a lane may use 256 registers, which pays for fetching the weights TWO stages
+// ahead (two register sets; the set is a compile-time choice, so the loop is unrolled over two chunks = six stages): a
+// fetch has a full stage of its own wave plus the co-resident workgroup's MFMAs to arrive before it is written to LDS.
+struct HaloCfg4 {
+  static constexpr int WN = 2, WM = 2;
+  static constexpr int TM = 64, TN = 64;
+  static constexpr int MB = 2, NB = 2;
+};
+
+template <int TR>
+__global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                   int chunks_per_split, int m_fastest) {
+  constexpr int BM = 128, BN = 128;
+  using Cfg = HaloCfg4;
+  constexpr int HMAX = 204;
+  constexpr int HL = (HMAX * 8 + 255) / 256;         // float4 per thread per chunk (7)
+  constexpr int BP = BN / 64;                        // weight rows per thread and tap (2)
+  constexpr int ASTAGE = HMAX * HB_STRIDE;
+  constexpr int BSTAGE = 3 * BN * HB_STRIDE;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[ASTAGE + 2 * BSTAGE];
+  __bf16* const Abuf = lds;
+  __bf16* const Bbuf = lds + ASTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = tid >> 3, scol = tid & 7;         // halo staging: 32 rows x 8 channel quads per pass
+  const int brow = tid >> 2, bcol = tid & 3;         // weight staging: 64 rows x 4 groups of 8 channels per pass
+  const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
+  const int HROWS = (TH + 2) * HW2;
+  const int H = p.Hi, W = p.Wi;
+  const int M = p.NB * H * W;
+  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  const int lid_all = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int ntiles_all = (int)gridDim.x / ksplit;
+  const int kz = lid_all / ntiles_all;
+  const int lid = lid_all - kz * ntiles_all;
+  const int ntiles_m = ntiles_all / ntiles_n;
+  const int tile_m = m_fastest ? lid % ntiles_m : lid / ntiles_n;
+  const int tile_n = m_fastest ? lid / ntiles_m : lid - tile_m * ntiles_n;
+  const int img = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - img * (tiles_x * tiles_y);
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  const bool conv = p.mode == MSEG_MODE_CONV;
+
+  int hpix[HL];
+  unsigned hvalid = 0u;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int hrow = srow + 32 * j;
+    const int hy = hrow / HW2, hx = hrow - hy * HW2;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+    hpix[j] = iy * W + ix;
+    hvalid |= (unsigned)ok << j;
+  }
+  int abase[Cfg::MB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a) {
+    const int i = wm * Cfg::TM + a * 32 + li;
+    abase[a] = ((i >> tw_log2) * HW2 + (i & (TW - 1))) * HB_STRIDE + lh * 8;
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+  const unsigned OOB = 0x80000000u;
+  const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
+  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
+                                                                        H * W * p.src[0].C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
+                                                                        H * W * C1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                        9 * p.Npad * p.Kpad * 2, 0x00020000);
+  const unsigned wvoff = ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u;
+  const unsigned wvstep = 64u * (unsigned)p.Kpad * 2u;                              // scalar: 64 weight rows further
+
+  float4 rh[HL], rsc, rsh;
+  f32x4 rbA[3][BP], rbB[3][BP];
+  unsigned hlive = 0u;
+  int ract = 0;
+  bool cur_s1 = false;
+
+  auto issue_halo = [&](int chunk) {
+    const int c = chunk * KC + scol * 4;
+    cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
+    const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
+    const unsigned sC4 = (unsigned)s.C * 4u;
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u + scol * 16u;
+    hlive = (c < p.Cin) ? hvalid : 0u;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const bool ok = (hlive >> j) & 1u;
+      const unsigned vo = ok ? (unsigned)hpix[j] * sC4 + soff : OOB;
+      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+      rh[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const unsigned cl = (c < p.Cin) ? (unsigned)(cur_s1 ? c - C0 : c) : 0u;
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
+      rsc = *reinterpret_cast<const float4*>(scp + o);
+      rsh = *reinterpret_cast<const float4*>(shp + o);
+    }
+  };
+
+  auto commit_halo = [&](__bf16* As) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const int hrow = srow + 32 * j;
+      if (hrow < HMAX) {
+        float4 v = rh[j];
+        if (TR != 0) {
+          if (TR == 2) v = act_fwd4(v, ract);
+          else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+          const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+          v.x = (v.x * rsc.x + rsh.x) * m; v.y = (v.y * rsc.y + rsh.y) * m;
+          v.z = (v.z * rsc.z + rsh.z) * m; v.w = (v.w * rsc.w + rsh.w) * m;
+        }
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
+      }
+    }
+  };
+
+  auto issue_b = [&](f32x4 (&rb)[3][BP], int chunk, int ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned wso = ((unsigned)(ky * 3 + kx) * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC) * 2u;
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        rb[kx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, wso + wvstep * i, 0));
+    }
+  };
+  auto commit_b = [&](const f32x4 (&rb)[3][BP], __bf16* Bs) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        *reinterpret_cast<f32x4*>(Bs + (kx * BN + brow + 64 * i) * HB_STRIDE + bcol * 8) = rb[kx][i];
+  };
+
+  const int c_begin = kz * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  // stage s = (chunk, kernel row): weights fetched two stages ahead into register set s & 1, written to LDS buffer s & 1
+  // at the end of stage s - 1; stages past the end re-read the last one (branch-free, harmless)
+  auto stage_at = [&](int chunk, int ky, int ahead, int& c2, int& k2) {
+    k2 = ky + ahead; c2 = chunk;
+    if (k2 >= 3) { k2 -= 3; c2 += 1; }
+    if (c2 >= c_end) { c2 = c_end - 1; k2 = 2; }
+  };
+  int bsel = 0;
+  {
+    int c1, k1;
+    issue_halo(c_begin);
+    issue_b(rbA, c_begin, 0);
+    stage_at(c_begin, 0, 1, c1, k1);
+    issue_b(rbB, c1, k1);
+    commit_halo(Abuf);
+    commit_b(rbA, Bbuf);
+    __syncthreads();
+  }
+#define MSEG_HB4_STAGE(FREE_, HELD_, chunk_, ky_)                                                                  \
+  {                                                                                                                \
+    const int chunk = (chunk_);                                                                                    \
+    constexpr int ky = (ky_);                                                                                      \
+    const bool more_chunks = chunk + 1 < c_end;                                                                    \
+    if (ky == 0 && more_chunks) issue_halo(chunk + 1);                                                             \
+    int c2, k2;                                                                                                    \
+    stage_at(chunk, ky, 2, c2, k2);                                                                                \
+    issue_b(FREE_, c2, k2);                                                                                        \
+    const __bf16* As = Abuf;                                                                                       \
+    const __bf16* Bs = Bbuf + bsel * BSTAGE;                                                                       \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                             \
+      const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * HB_STRIDE;                            \
+      _Pragma("unroll") for (int kk = 0; kk < KC / 16; ++kk) {                                                     \
+        bf16x8 af[Cfg::MB], bf[Cfg::NB];                                                                           \
+        _Pragma("unroll") for (int a = 0; a < Cfg::MB; ++a)                                                        \
+          af[a] = *reinterpret_cast<const bf16x8*>(As + abase[a] + toff + kk * 16);                                \
+        _Pragma("unroll") for (int b = 0; b < Cfg::NB; ++b)                                                        \
+          bf[b] = *reinterpret_cast<const bf16x8*>(Bs + (kx * BN + wn * Cfg::TN + b * 32 + li) * HB_STRIDE +      \
+                                                   kk * 16 + lh * 8);                                              \
+        _Pragma("unroll") for (int a = 0; a < Cfg::MB; ++a)                                                        \
+          _Pragma("unroll") for (int b = 0; b < Cfg::NB; ++b)                                                      \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);                 \
+      }                                                                                                            \
+    }                                                                                                              \
+    commit_b(HELD_, Bbuf + (bsel ^ 1) * BSTAGE);                                                                   \
+    if (ky == 2 && more_chunks) {                                                                                  \
+      __syncthreads();                                                                                             \
+      commit_halo(Abuf);                                                                                           \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    bsel ^= 1;                                                                                                     \
+  }
+  int chunk0 = c_begin;
+  for (; chunk0 + 1 < c_end; chunk0 += 2) {
+    MSEG_HB4_STAGE(rbA, rbB, chunk0, 0)
+    MSEG_HB4_STAGE(rbB, rbA, chunk0, 1)
+    MSEG_HB4_STAGE(rbA, rbB, chunk0, 2)
+    MSEG_HB4_STAGE(rbB, rbA, chunk0 + 1, 0)
+    MSEG_HB4_STAGE(rbA, rbB, chunk0 + 1, 1)
+    MSEG_HB4_STAGE(rbB, rbA, chunk0 + 1, 2)
+  }
+  if (chunk0 < c_end) {
+    MSEG_HB4_STAGE(rbA, rbB, chunk0, 0)
+    MSEG_HB4_STAGE(rbB, rbA, chunk0, 1)
+    MSEG_HB4_STAGE(rbA, rbB, chunk0, 2)
+  }
+#undef MSEG_HB4_STAGE
+  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
+}
+
 // ---- bf16 variant of the gather kernel (stride-2 convolutions, ConvTranspose as a 1x1 GEMM, their data gradients) ----
 // igemm_fast_kernel with bf16 matrix-core inputs: same per-row offsets / tap masks / live-tap list and epilogue; the staged
 // source pixels are rounded to bf16 after the norm-on-load transform, the weights arrive as bf16, LDS rows are 32 bf16 +
@@ -1488,13 +1721,16 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const int m_fastest = ((long long)9 * p.Kpad * p.Ngemm * 2 > (2ll << 20)) && (p.Ngemm > BNv) ? 1 : 0;
 #define MSEG_HALO16(BN_, TR_) \
   hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest)
+#define MSEG_HALO16W4(TR_) \
+  hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest)
     if (p.precision == MSEG_PREC_BF16) {
-      if (wide) { if (tr == 0) MSEG_HALO16(128, 0); else if (tr == 1) MSEG_HALO16(128, 1); else MSEG_HALO16(128, 2); }
+      if (wide) { if (tr == 0) MSEG_HALO16W4(0); else if (tr == 1) MSEG_HALO16W4(1); else MSEG_HALO16W4(2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }
     } else if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }
     else      { if (tr == 0) MSEG_HALO(64, 0); else if (tr == 1) MSEG_HALO(64, 1); else MSEG_HALO(64, 2); }
 #undef MSEG_HALO
 #undef MSEG_HALO16
+#undef MSEG_HALO16W4
     MSEG_LAUNCH_CHECK();
     if (ks > 1) {
       const size_t total = (size_t)M * (size_t)(p.Ngemm >> 2);

@@ -319,8 +319,8 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
                               parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0))
     if bf16:
-        name = name.replace("igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel",
-                                                                                  "igemm_fast_bf16_kernel")
+        name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
+            "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")
     e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
