@@ -38,12 +38,14 @@ def _step(net, batch, dev):
     return {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, precision="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from microbeseg_amd import engine
         from microbeseg_amd.utils.unets import build_unet
+        engine.set_precision(precision)
         dev = torch.device("cuda:0")
         torch.manual_seed(123 + rank)       # replicas start different; the wrapper must broadcast rank 0's weights
         net = build_unet("DU", "relu", "conv", "bn", dev, world, filters=FILTERS)
@@ -54,12 +56,16 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_rank_gradient_average(precision, request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    from microbeseg_amd import engine
+    request.addfinalizer(lambda: engine.set_precision("fp32"))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, precision), nprocs=2, join=True)
+    engine.set_precision(precision)          # the single-process reference below runs in the same mode
     (g0, sd0), (g1, sd1) = ret[0], ret[1]
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k                       # every rank holds the same averaged gradient
