@@ -274,6 +274,11 @@ int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uin
 size_t mseg_label_distance_workspace_bytes(int N, int H, int W);
 int mseg_label_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float* cell_out,
                         float* neighbor_out, void* ws, size_t ws_bytes, void* stream);
+/* cell_distance_label(label, search_radius, apply_clipping, clip_val) of train_data_representations.py:219-258: the cell
+ * distances alone; clip_val == 0: normalised per cell (label types 'cell_dist'), > 0: min(d, clip_val) / clip_val
+ * ('cell_dist_clipped', clip_val 5).  Same workspace as mseg_label_distance.                                          */
+int mseg_label_cell_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float clip_val,
+                             float* cell_out, void* ws, size_t ws_bytes, void* stream);
 /* Largest skimage regionprops major_axis_length over the cells of each mask (CreateLabelsWorker.create_labels,
  * src/training/train.py:73-78, which sets search_radius = ceil(0.75 * ceil(max major axis))): out_dev double [N].    */
 size_t mseg_label_major_axis_workspace_bytes(int N);

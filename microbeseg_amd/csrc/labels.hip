@@ -195,9 +195,11 @@ __global__ void lb_edt_kernel(const uint16_t* __restrict__ mask, int N, int H, i
   }
 }
 
+// clip > 0: cell_distance_label(..., apply_clipping=True, clip_val=clip): min(distance, clip) / clip instead of the
+// per-cell normalisation (train_data_representations.py:245-256); nb may be NULL (cell distances only)
 __global__ void lb_value_kernel(const uint16_t* __restrict__ mask, int N, int H, int W, const LbCell* __restrict__ cells,
                                 const int32_t* __restrict__ d2c, const int32_t* __restrict__ d2n, float* __restrict__ cell,
-                                double* __restrict__ nb) {
+                                double* __restrict__ nb, double clip) {
   const size_t hw = (size_t)H * W, n = (size_t)N * hw;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
     const int k = mask[t];
@@ -208,7 +210,7 @@ __global__ void lb_value_kernel(const uint16_t* __restrict__ mask, int N, int H,
       const int bc = d2c[t], bn = d2n[t];
       if (bc > 0 && c->maxc > 0) {
         const double dmax = sqrt((double)c->maxc);
-        cv = (float)(sqrt((double)bc) / dmax);
+        cv = clip > 0.0 ? (float)(fmin(sqrt((double)bc), clip) / clip) : (float)(sqrt((double)bc) / dmax);
         if (bn > 0) {
           const double den = fmin(dmax + 3.0, sqrt((double)c->maxn));
           nv = 1.0 - fmin(sqrt((double)bn) / den, 1.0);
@@ -216,7 +218,7 @@ __global__ void lb_value_kernel(const uint16_t* __restrict__ mask, int N, int H,
       }
     }
     cell[t] = cv;
-    nb[t] = nv;
+    if (nb) nb[t] = nv;
   }
 }
 
@@ -531,7 +533,7 @@ extern "C" int mseg_label_distance(const uint16_t* mask, int N, int H, int W, in
   hipLaunchKernelGGL(lb_window_kernel, dim3(lb_blocks((size_t)N * LB_IDS)), dim3(LB_BLOCK), 0, st, cells, N, H, W,
                      search_radius);
   hipLaunchKernelGGL(lb_edt_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, prevd, nextd, cells, d2c, d2n);
-  hipLaunchKernelGGL(lb_value_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, cells, d2c, d2n, cell_out, nb);
+  hipLaunchKernelGGL(lb_value_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, cells, d2c, d2n, cell_out, nb, 0.0);
   hipLaunchKernelGGL(lb_close_cells_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, bin);
   hipLaunchKernelGGL(lb_disk_kernel<false>, dim3(nbk), dim3(LB_BLOCK), 0, st, bin, bin, N, H, W, tmp);
   hipLaunchKernelGGL(lb_disk_kernel<true>, dim3(nbk), dim3(LB_BLOCK), 0, st, tmp, bin, N, H, W, gap);
@@ -544,6 +546,34 @@ extern "C" int mseg_label_distance(const uint16_t* mask, int N, int H, int W, in
   hipLaunchKernelGGL(lb_final_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, L, gaps, nb, N, H, W, f0);
   hipLaunchKernelGGL(lb_grey3_kernel<true>, dim3(nbk), dim3(LB_BLOCK), 0, st, f0, N, H, W, f1);
   hipLaunchKernelGGL(lb_grey3_kernel<false>, dim3(nbk), dim3(LB_BLOCK), 0, st, f1, N, H, W, neighbor_out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// cell_distance_label (train_data_representations.py:219-258): the cell-distance half alone, optionally clipped
+extern "C" int mseg_label_cell_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float clip_val,
+                                        float* cell_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!mask || !cell_out || !ws || search_radius <= 0 || clip_val < 0.f) return MSEG_EINVAL;
+  const size_t need = mseg_label_distance_workspace_bytes(N, H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const LbLayout l = lb_layout(N, H, W);
+  char* base = (char*)ws;
+  LbCell* cells = (LbCell*)(base + l.cells);
+  int32_t* prevd = (int32_t*)(base + l.prevd);
+  int32_t* nextd = (int32_t*)(base + l.nextd);
+  int32_t* d2c = (int32_t*)(base + l.d2c);
+  int32_t* d2n = (int32_t*)(base + l.d2n);
+  const unsigned nbk = lb_blocks((size_t)N * H * W);
+  if (hipMemsetAsync(cells, 0, (size_t)N * LB_IDS * sizeof(LbCell), st) != hipSuccess) return MSEG_ELAUNCH;
+  hipLaunchKernelGGL(lb_runs_kernel, dim3((N * H + 63) / 64), dim3(64), 0, st, mask, N, H, W, prevd, nextd);
+  hipLaunchKernelGGL(lb_props_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, cells);
+  hipLaunchKernelGGL(lb_window_kernel, dim3(lb_blocks((size_t)N * LB_IDS)), dim3(LB_BLOCK), 0, st, cells, N, H, W,
+                     search_radius);
+  hipLaunchKernelGGL(lb_edt_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, prevd, nextd, cells, d2c, d2n);
+  hipLaunchKernelGGL(lb_value_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, cells, d2c, d2n, cell_out,
+                     (double*)nullptr, (double)clip_val);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

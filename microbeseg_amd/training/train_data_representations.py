@@ -7,8 +7,8 @@ distance transform; two binary closings per cell over the whole image).  Here th
 streaming kernel over the mask batch (csrc/augment.hip: ``mseg_label_boundary``) and the distance labels a fixed sequence
 of passes over the pixel batch (csrc/labels.hip: ``mseg_label_distance``): exact integer distances by a row sweep over
 run ends, closings with the radius-3 disk, union-find gap components, per-gap moments and rim sums by atomics.
-``get_label`` raises for the reference's experimental label types (adapted_border, j4, cell_dist*), which microbeSEG's
-training never requests.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
+``get_label`` also serves the reference's ``cell_dist`` / ``cell_dist_clipped`` types (``cell_distance_label``) and raises
+for ``adapted_border`` (OpenCV morphology) and ``j4``, which microbeSEG's training never requests.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
 """
 import numpy as np
 import torch
@@ -94,6 +94,33 @@ def distance_label(label, search_radius):
     return cell[0], nb[0]
 
 
+def cell_distance_label(label, search_radius, apply_clipping=False, clip_val=5):
+    """ Cell distance label creation (Euclidean distance), reference :219-258: the per-cell normalised distance
+    transform alone, or (apply_clipping) min(distance, clip_val) / clip_val.  float32 (H, W). """
+    if not torch.cuda.is_available():
+        raise RuntimeError("microbeseg_amd label creation needs the MI355X HIP path (no CPU fallback)")
+    lib = _lib.load()
+    a = np.ascontiguousarray(label)
+    if a.ndim != 2:
+        raise RuntimeError("expected a 2-D intensity-coded instance mask")
+    if a.min(initial=0) < 0 or a.max(initial=0) > 65535:
+        raise RuntimeError("instance ids must fit uint16")
+    if int(search_radius) <= 0 or (apply_clipping and clip_val <= 0):
+        raise RuntimeError("search_radius and clip_val must be positive")
+    H, W = a.shape
+    dev = torch.device("cuda", torch.cuda.current_device())
+    need = lib.mseg_label_distance_workspace_bytes(1, H, W)
+    if need == 0:
+        raise RuntimeError(f"unsupported mask shape {H}x{W}")
+    m = torch.from_numpy(a.astype(np.uint16).view(np.int16)).to(dev)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = torch.empty((H, W), dtype=torch.float32, device=dev)
+    _lib.check(lib.mseg_label_cell_distance(m.data_ptr(), 1, H, W, int(search_radius),
+                                            float(clip_val) if apply_clipping else 0.0, out.data_ptr(), ws.data_ptr(), need,
+                                            torch.cuda.current_stream().cuda_stream), "label_cell_distance")
+    return out.cpu().numpy()
+
+
 def max_major_axis_length(mask):
     """ Largest ``regionprops(mask)[i].major_axis_length`` of an instance mask (what create_labels turns into max_mal,
     reference src/training/train.py:73-78); 0.0 for an empty mask. """
@@ -123,7 +150,11 @@ def get_label(mask, label_type, max_mal):
         return border_label(mask)
     if label_type == 'distance':
         return distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)))
-    if label_type in ('adapted_border', 'j4', 'cell_dist', 'cell_dist_clipped'):
+    if label_type == 'cell_dist':
+        return cell_distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)))
+    if label_type == 'cell_dist_clipped':
+        return cell_distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)), apply_clipping=True)
+    if label_type in ('adapted_border', 'j4'):
         raise RuntimeError(f"label type '{label_type}' is not part of the MI355X build yet (SURVEY.md §8f n2): create it "
                            "with the reference's train_data_representations.py")
     raise Exception('Label type not known')

@@ -140,3 +140,26 @@ def major_axis_lengths(label):
         a, c, b = (y * y).mean(), (x * x).mean(), (x * y).mean()
         out.append(4.0 * np.sqrt(0.5 * (a + c) + 0.5 * np.sqrt(4 * b * b + (a - c) ** 2)))
     return np.array(out, np.float64)
+
+
+def cell_distance_label(label, search_radius, apply_clipping=False, clip_val=5):
+    """cell_distance_label (:219-258): the per-cell windowed distance transform, normalised per cell or clipped"""
+    from scipy import ndimage as ndi
+    lab = np.asarray(label).astype(np.int64)
+    H, W = lab.shape
+    sr = int(search_radius)
+    out = np.zeros((H, W), np.float64)
+    for k in np.unique(lab):
+        if k == 0:
+            continue
+        ys, xs = np.nonzero(lab == k)
+        cy, cx = np.round(ys.mean()), np.round(xs.mean())
+        y0, y1 = int(max(cy - sr, 0)), int(min(cy + sr, H))
+        x0, x1 = int(max(cx - sr, 0)), int(min(cx + sr, W))
+        d = ndi.distance_transform_edt(lab[y0:y1, x0:x1] == k)
+        if d.size and d.max() > 0 and not apply_clipping:
+            d = d / d.max()
+        out[y0:y1, x0:x1] += d
+    if apply_clipping:
+        out = np.clip(out, 0, clip_val) / clip_val
+    return out.astype(np.float32)

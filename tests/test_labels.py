@@ -180,3 +180,27 @@ def test_create_labels_worker(tmp_path):
     w2.stop_label_creation_process()
     w2.create_labels(root2, "distance")
     assert not root2.exists()
+
+
+@pytest.mark.parametrize("i", DCASES)
+def test_cell_distance_oracle_matches_reference(i):
+    m, sr = GD[f"m{i}"], int(GD[f"sr{i}"])
+    assert np.array_equal(labels_ref.cell_distance_label(m, sr), GD[f"celld{i}"])
+    assert np.array_equal(labels_ref.cell_distance_label(m, sr, apply_clipping=True), GD[f"cellc{i}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", DCASES)
+def test_cell_distance_hip_matches_reference(i):
+    """label types 'cell_dist' / 'cell_dist_clipped' (cell_distance_label, reference :219-258)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    m, sr = GD[f"m{i}"], int(GD[f"sr{i}"])
+    assert np.abs(T.cell_distance_label(m, sr) - GD[f"celld{i}"]).max() <= DTOL
+    assert np.abs(T.cell_distance_label(m, sr, apply_clipping=True) - GD[f"cellc{i}"]).max() <= DTOL
+    # dispatcher: the search radius is ceil(0.75 * max_mal), so max_mal = sr / 0.75 rounded down reproduces sr
+    mm = int(sr / 0.75)
+    if int(np.ceil(0.75 * mm)) == sr:
+        assert np.abs(T.get_label(m, "cell_dist", mm) - GD[f"celld{i}"]).max() <= DTOL
+        assert np.abs(T.get_label(m, "cell_dist_clipped", mm) - GD[f"cellc{i}"]).max() <= DTOL

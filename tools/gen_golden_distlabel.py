@@ -16,7 +16,7 @@ np.float = float
 sys.dont_write_bytecode = True
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
 sys.path.insert(0, "/root/reference")
-from src.training.train_data_representations import distance_label, bottom_hat_closing  # noqa: E402
+from src.training.train_data_representations import distance_label, bottom_hat_closing, cell_distance_label  # noqa: E402
 
 OUT = pathlib.Path(__file__).resolve().parents[1] / "tests" / "golden"
 
@@ -55,6 +55,8 @@ for i, (H, W, n, r0, r1, gap, sr) in enumerate(cases):
     out[f"neighbor{i}"] = nb
     out[f"closed{i}"] = closed.astype(np.int32)
     out[f"corr{i}"] = corr.astype(np.float32)
+    out[f"celld{i}"] = cell_distance_label(m.copy(), sr)
+    out[f"cellc{i}"] = cell_distance_label(m.copy(), sr, apply_clipping=True)
     # the search radius of the label creation comes from the largest major axis (src/training/train.py:73-78)
     from skimage.measure import regionprops
     out[f"mal{i}"] = np.array([c.major_axis_length for c in regionprops(m.astype(np.int32))], np.float64)
