@@ -274,6 +274,11 @@ int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uin
 size_t mseg_label_distance_workspace_bytes(int N, int H, int W);
 int mseg_label_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float* cell_out,
                         float* neighbor_out, void* ws, size_t ws_bytes, void* stream);
+/* j4_label(label, k_neighbors, se_radius) of train_data_representations.py:157-216 (Pena et al. 2020): 0 background,
+ * 1 cell, 2 touching (another instance inside the (2k+1)^2 window), 3 gap (bottom-hat with disk(se_radius)); uint8.
+ * tmp: device scratch of N*H*W bytes.                                                                                 */
+int mseg_label_j4(const uint16_t* mask, int N, int H, int W, int k_neighbors, int se_radius, uint8_t* tmp, uint8_t* out,
+                  void* stream);
 /* cell_distance_label(label, search_radius, apply_clipping, clip_val) of train_data_representations.py:219-258: the cell
  * distances alone; clip_val == 0: normalised per cell (label types 'cell_dist'), > 0: min(d, clip_val) / clip_val
  * ('cell_dist_clipped', clip_val 5).  Same workspace as mseg_label_distance.                                          */

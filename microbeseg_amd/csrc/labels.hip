@@ -550,6 +550,77 @@ extern "C" int mseg_label_distance(const uint16_t* mask, int N, int H, int W, in
   return MSEG_OK;
 }
 
+// ---- j4_label (train_data_representations.py:157-188; Pena et al., ISBI 2020): background / cell / touching / gap -------------
+// gap = bottom-hat of the binary mask with disk(se_radius) (closing ^ mask; scipy's border_value 0), touching = cell pixels
+// whose (2k+1)^2 window holds more than one instance id (compute_neighbor_instances :191-216).  0 background, 1 cell,
+// 2 touching, 3 gap.  Two passes: dilation of the binary mask, then erosion + neighbour count + classification.
+__global__ void lb_j4_dilate_kernel(const uint16_t* __restrict__ mask, int N, int H, int W, int R, uint8_t* __restrict__ dil) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = t / hw;
+    const int r = (int)(t - s * hw);
+    const int y = r / W, x = r - y * W;
+    const uint16_t* m = mask + s * hw;
+    bool v = false;
+    for (int dy = -R; dy <= R && !v; ++dy)
+      for (int dx = -R; dx <= R; ++dx) {
+        if (dy * dy + dx * dx > R * R) continue;
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W && m[(size_t)yy * W + xx]) { v = true; break; }
+      }
+    dil[t] = v ? 1 : 0;
+  }
+}
+
+__global__ void lb_j4_final_kernel(const uint16_t* __restrict__ mask, const uint8_t* __restrict__ dil, int N, int H, int W,
+                                   int R, int K, uint8_t* __restrict__ out) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = t / hw;
+    const int r = (int)(t - s * hw);
+    const int y = r / W, x = r - y * W;
+    const uint16_t* m = mask + s * hw;
+    const uint8_t* d = dil + s * hw;
+    const int lab = m[r];
+    uint8_t cls;
+    if (lab) {
+      // distinct ids in the (2K+1)^2 window (zero padded): more than one -> touching
+      bool other = false;
+      for (int dy = -K; dy <= K && !other; ++dy)
+        for (int dx = -K; dx <= K; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          const int q = m[(size_t)yy * W + xx];
+          if (q && q != lab) { other = true; break; }
+        }
+      cls = other ? 2 : 1;
+    } else {
+      bool closed = true;                              // erosion of the dilated mask; outside the image counts as empty
+      for (int dy = -R; dy <= R && closed; ++dy)
+        for (int dx = -R; dx <= R; ++dx) {
+          if (dy * dy + dx * dx > R * R) continue;
+          const int yy = y + dy, xx = x + dx;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= W || !d[(size_t)yy * W + xx]) { closed = false; break; }
+        }
+      cls = closed ? 3 : 0;
+    }
+    out[t] = cls;
+  }
+}
+
+extern "C" int mseg_label_j4(const uint16_t* mask, int N, int H, int W, int k_neighbors, int se_radius, uint8_t* tmp,
+                             uint8_t* out, void* stream) {
+  if (!mask || !tmp || !out || N <= 0 || H <= 0 || W <= 0 || k_neighbors < 0 || k_neighbors > 16 || se_radius < 1 ||
+      se_radius > 16)
+    return MSEG_EINVAL;
+  const unsigned nbk = lb_blocks((size_t)N * H * W);
+  hipLaunchKernelGGL(lb_j4_dilate_kernel, dim3(nbk), dim3(LB_BLOCK), 0, (hipStream_t)stream, mask, N, H, W, se_radius, tmp);
+  hipLaunchKernelGGL(lb_j4_final_kernel, dim3(nbk), dim3(LB_BLOCK), 0, (hipStream_t)stream, mask, (const uint8_t*)tmp, N, H,
+                     W, se_radius, k_neighbors, out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
 // cell_distance_label (train_data_representations.py:219-258): the cell-distance half alone, optionally clipped
 extern "C" int mseg_label_cell_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float clip_val,
                                         float* cell_out, void* ws, size_t ws_bytes, void* stream) {

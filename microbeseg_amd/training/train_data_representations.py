@@ -7,8 +7,8 @@ distance transform; two binary closings per cell over the whole image).  Here th
 streaming kernel over the mask batch (csrc/augment.hip: ``mseg_label_boundary``) and the distance labels a fixed sequence
 of passes over the pixel batch (csrc/labels.hip: ``mseg_label_distance``): exact integer distances by a row sweep over
 run ends, closings with the radius-3 disk, union-find gap components, per-gap moments and rim sums by atomics.
-``get_label`` also serves the reference's ``cell_dist`` / ``cell_dist_clipped`` types (``cell_distance_label``) and raises
-for ``adapted_border`` (OpenCV morphology) and ``j4``, which microbeSEG's training never requests.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
+``get_label`` also serves the reference's ``cell_dist`` / ``cell_dist_clipped`` (``cell_distance_label``) and ``j4`` types and
+raises for ``adapted_border`` (OpenCV Canny edges), which microbeSEG's training never requests.  No CPU fallback (oracle/labels_ref.py is the CPU checker of the tests).
 """
 import numpy as np
 import torch
@@ -121,6 +121,25 @@ def cell_distance_label(label, search_radius, apply_clipping=False, clip_val=5):
     return out.cpu().numpy()
 
 
+def j4_label(label, k_neighbors=2, se_radius=4):
+    """ Pena label creation for the J4 method (0 background, 1 cell, 2 touching, 3 gap), reference :157-216. """
+    if not torch.cuda.is_available():
+        raise RuntimeError("microbeseg_amd label creation needs the MI355X HIP path (no CPU fallback)")
+    lib = _lib.load()
+    a = np.ascontiguousarray(label)
+    if a.ndim != 2:
+        raise RuntimeError("expected a 2-D intensity-coded instance mask")
+    if a.min(initial=0) < 0 or a.max(initial=0) > 65535:
+        raise RuntimeError("instance ids must fit uint16")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m = torch.from_numpy(a.astype(np.uint16).view(np.int16)).to(dev)
+    tmp = torch.empty(a.shape, dtype=torch.uint8, device=dev)
+    out = torch.empty(a.shape, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mseg_label_j4(m.data_ptr(), 1, a.shape[0], a.shape[1], int(k_neighbors), int(se_radius), tmp.data_ptr(),
+                                 out.data_ptr(), torch.cuda.current_stream().cuda_stream), "label_j4")
+    return out.cpu().numpy()
+
+
 def max_major_axis_length(mask):
     """ Largest ``regionprops(mask)[i].major_axis_length`` of an instance mask (what create_labels turns into max_mal,
     reference src/training/train.py:73-78); 0.0 for an empty mask. """
@@ -154,7 +173,9 @@ def get_label(mask, label_type, max_mal):
         return cell_distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)))
     if label_type == 'cell_dist_clipped':
         return cell_distance_label(mask, search_radius=int(np.ceil(0.75 * max_mal)), apply_clipping=True)
-    if label_type in ('adapted_border', 'j4'):
+    if label_type == 'j4':
+        return j4_label(mask)
+    if label_type in ('adapted_border',):
         raise RuntimeError(f"label type '{label_type}' is not part of the MI355X build yet (SURVEY.md §8f n2): create it "
                            "with the reference's train_data_representations.py")
     raise Exception('Label type not known')

@@ -163,3 +163,27 @@ def cell_distance_label(label, search_radius, apply_clipping=False, clip_val=5):
     if apply_clipping:
         out = np.clip(out, 0, clip_val) / clip_val
     return out.astype(np.float32)
+
+
+def j4_label(label, k_neighbors=2, se_radius=4):
+    """j4_label (:157-216): 0 background, 1 cell, 2 touching, 3 gap"""
+    from scipy import ndimage as ndi
+    lab = np.asarray(label).astype(np.int64)
+    H, W = lab.shape
+    fg = lab > 0
+    r = np.arange(-se_radius, se_radius + 1)
+    se = (r[:, None] ** 2 + r[None, :] ** 2) <= se_radius ** 2
+    gap = (ndi.binary_closing(fg, se) ^ fg) & ~fg
+    k = k_neighbors
+    pad = np.zeros((H + 2 * k, W + 2 * k), np.int64)
+    pad[k:k + H, k:k + W] = lab
+    other = np.zeros((H, W), bool)                    # another instance id somewhere in the (2k+1)^2 window
+    for dy in range(2 * k + 1):
+        for dx in range(2 * k + 1):
+            q = pad[dy:dy + H, dx:dx + W]
+            other |= (q > 0) & (q != lab)
+    out = np.zeros((H, W), np.uint8)
+    out[fg] = 1
+    out[fg & other] = 2
+    out[gap] = 3
+    return out

@@ -44,7 +44,7 @@ def test_hip_matches_oracle_random():
     assert np.array_equal(T.boundary_label(m), labels_ref.boundary_label(m))
     assert np.array_equal(T.border_label(m), labels_ref.border_label(m))
     with pytest.raises(RuntimeError):
-        T.get_label(m, "j4", 20)
+        T.get_label(m, "adapted_border", 20)
 
 
 # ---- distance labels ---------------------------------------------------------------------------------------------------
@@ -204,3 +204,23 @@ def test_cell_distance_hip_matches_reference(i):
     if int(np.ceil(0.75 * mm)) == sr:
         assert np.abs(T.get_label(m, "cell_dist", mm) - GD[f"celld{i}"]).max() <= DTOL
         assert np.abs(T.get_label(m, "cell_dist_clipped", mm) - GD[f"cellc{i}"]).max() <= DTOL
+
+
+@pytest.mark.parametrize("i", DCASES)
+def test_j4_oracle_matches_reference(i):
+    assert np.array_equal(labels_ref.j4_label(GD[f"m{i}"]), GD[f"j4{i}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", DCASES)
+def test_j4_hip_matches_reference(i):
+    """label type 'j4' (Pena et al.): background / cell / touching / gap, exact"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    got = T.get_label(GD[f"m{i}"], "j4", 0)
+    assert got.dtype == np.uint8 and np.array_equal(got, GD[f"j4{i}"])
+    m = GD[f"m{i}"]
+    assert np.array_equal(T.j4_label(m, k_neighbors=1, se_radius=2), labels_ref.j4_label(m, 1, 2))
+    with pytest.raises(RuntimeError):
+        T.get_label(m, "adapted_border", 0)

@@ -16,7 +16,8 @@ np.float = float
 sys.dont_write_bytecode = True
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
 sys.path.insert(0, "/root/reference")
-from src.training.train_data_representations import distance_label, bottom_hat_closing, cell_distance_label  # noqa: E402
+from src.training.train_data_representations import (distance_label, bottom_hat_closing, cell_distance_label,  # noqa: E402
+                                                     j4_label)
 
 OUT = pathlib.Path(__file__).resolve().parents[1] / "tests" / "golden"
 
@@ -57,6 +58,7 @@ for i, (H, W, n, r0, r1, gap, sr) in enumerate(cases):
     out[f"corr{i}"] = corr.astype(np.float32)
     out[f"celld{i}"] = cell_distance_label(m.copy(), sr)
     out[f"cellc{i}"] = cell_distance_label(m.copy(), sr, apply_clipping=True)
+    out[f"j4{i}"] = j4_label(m.astype(np.int32))
     # the search radius of the label creation comes from the largest major axis (src/training/train.py:73-78)
     from skimage.measure import regionprops
     out[f"mal{i}"] = np.array([c.major_axis_length for c in regionprops(m.astype(np.int32))], np.float64)
