@@ -116,3 +116,124 @@ def aji_plus_masks(prediction, ground_truth, border_width=10):
         return 0
     g_lab, n_g = relabel_device(ground_truth, border_width)
     return _aji_from_counts(*pair_counts_device(g_lab, p_lab, n_g, n_p))
+
+
+# ---- the other HoVer-Net metrics of the reference module (stats_utils.py:16-95, 183-437) -------------------------------------
+# EvalWorker only calls get_fast_aji_plus; these share its integer statistics (areas + pairwise intersections from
+# mseg_eval_pair_counts), so each is a short formula on the small (instances x instances) matrices.  Like the reference
+# functions they expect contiguous ids 1..n (call remap_label first).
+
+def _prep_pair(true, pred):
+    dev = true.device if isinstance(true, torch.Tensor) and true.is_cuda else _device()
+
+    def prep(a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=dev, dtype=torch.int32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
+    t, p = prep(true), prep(pred)
+    nt, npd = int(t.max().item()), int(p.max().item())
+    return pair_counts_device(t, p, nt, npd)
+
+
+def get_fast_aji(true, pred):
+    """AJI as distributed by MoNuSeg (reference :16-95): every ground-truth instance is paired with the prediction of
+    highest IoU, predictions may be reused."""
+    area_t, area_p, inter = _prep_pair(true, pred)
+    nt, npd = len(area_t) - 1, len(area_p) - 1
+    pairwise_inter = inter[1:, 1:].astype(np.float64)
+    pairwise_union = (area_t[1:, None] + area_p[None, 1:]).astype(np.float64) - pairwise_inter
+    pairwise_union[pairwise_inter == 0] = 0.0
+    pairwise_iou = pairwise_inter / (pairwise_union + 1.0e-6)
+    best = np.argmax(pairwise_iou, axis=1)            # raises on an empty prediction, like the reference
+    best_iou = np.max(pairwise_iou, axis=1)
+    paired_true = np.nonzero(best_iou > 0.0)[0]
+    paired_pred = best[paired_true]
+    overall_inter = pairwise_inter[paired_true, paired_pred].sum()
+    overall_union = pairwise_union[paired_true, paired_pred].sum()
+    overall_union += area_t[1:][np.setdiff1d(np.arange(nt), paired_true)].sum()
+    overall_union += area_p[1:][np.setdiff1d(np.arange(npd), paired_pred)].sum()
+    return overall_inter / overall_union
+
+
+def get_fast_pq(true, pred, match_iou=0.5):
+    """Panoptic quality (reference :183-285).  Returns [dq, sq, pq], [paired_true, paired_pred, unpaired_true,
+    unpaired_pred] (instance ids)."""
+    assert match_iou >= 0.0, "Cant' be negative"
+    area_t, area_p, inter = _prep_pair(true, pred)
+    nt, npd = len(area_t) - 1, len(area_p) - 1
+    pairwise_inter = inter[1:, 1:].astype(np.float64)
+    total = (area_t[1:, None] + area_p[None, 1:]).astype(np.float64)
+    pairwise_iou = np.where(pairwise_inter > 0, pairwise_inter / (total - pairwise_inter), 0.0)
+    if match_iou >= 0.5:                              # IoU > 0.5 pairs are unique and maximal
+        pairwise_iou[pairwise_iou <= match_iou] = 0.0
+        paired_true, paired_pred = np.nonzero(pairwise_iou)
+        paired_iou = pairwise_iou[paired_true, paired_pred]
+        paired_true = paired_true + 1
+        paired_pred = paired_pred + 1
+    else:                                             # maximal unique pairing, then threshold
+        rows, cols = linear_sum_assignment(-pairwise_iou)
+        paired_iou = pairwise_iou[rows, cols]
+        keep = paired_iou > match_iou
+        paired_true = list(rows[keep] + 1)
+        paired_pred = list(cols[keep] + 1)
+        paired_iou = paired_iou[keep]
+    unpaired_true = [i for i in range(1, nt + 1) if i not in paired_true]
+    unpaired_pred = [i for i in range(1, npd + 1) if i not in paired_pred]
+    tp, fp, fn = len(paired_true), len(unpaired_pred), len(unpaired_true)
+    dq = tp / (tp + 0.5 * fp + 0.5 * fn)
+    sq = paired_iou.sum() / (tp + 1.0e-6)
+    return [dq, sq, dq * sq], [paired_true, paired_pred, unpaired_true, unpaired_pred]
+
+
+def get_fast_dice_2(true, pred):
+    """Ensemble dice (reference :288-325): over all overlapping (true, pred) pairs."""
+    area_t, area_p, inter = _prep_pair(true, pred)
+    pairwise_inter = inter[1:, 1:]
+    overlapping = pairwise_inter > 0
+    overall_total = ((area_t[1:, None] + area_p[None, 1:]) * overlapping).sum()
+    overall_inter = pairwise_inter.sum()
+    return 2 * overall_inter / overall_total
+
+
+def get_dice_2(true, pred):
+    """Ensemble Dice as used in the Computational Precision Medicine Challenge (reference :341-362): the same number as
+    get_fast_dice_2."""
+    return get_fast_dice_2(true, pred)
+
+
+def get_dice_1(true, pred):
+    """Traditional dice of the binarised masks (reference :328-338)."""
+    area_t, area_p, inter = _prep_pair(true, pred)
+    return 2.0 * inter[1:, 1:].sum() / (area_t[1:].sum() + area_p[1:].sum())
+
+
+def remap_label(pred, by_size=False):
+    """Rename the instance ids to 1..n (order preserved, or bigger instances first with by_size), reference :365-395.
+    A lookup-table pass on the device (histogram + gather through torch: no arithmetic worth a kernel)."""
+    dev = _device()
+    a = np.ascontiguousarray(pred)
+    if a.min(initial=0) < 0:
+        raise RuntimeError("instance ids must be non-negative")
+    t = torch.from_numpy(a.astype(np.int64)).to(dev)
+    counts = torch.bincount(t.flatten())
+    ids = torch.nonzero(counts[1:] > 0).flatten() + 1
+    if ids.numel() == 0:
+        return pred                                  # no label, like the reference
+    if by_size:
+        order = torch.sort(counts[ids], descending=True, stable=True).indices
+        ids = ids[order]
+    lut = torch.zeros(counts.numel(), dtype=torch.int32, device=dev)
+    lut[ids] = torch.arange(1, ids.numel() + 1, dtype=torch.int32, device=dev)
+    return lut[t].cpu().numpy()
+
+
+def pair_coordinates(setA, setB, radius):
+    """Optimal unique pairing of two point sets within `radius` (reference :398-437; point-set arithmetic on the host, as
+    in the reference: scipy's cdist + linear_sum_assignment).  Returns pairing (K, 2), unpairedA, unpairedB."""
+    from scipy.spatial.distance import cdist
+    cost = cdist(setA, setB, metric='euclidean')
+    ia, ib = linear_sum_assignment(cost)
+    ok = cost[ia, ib] <= radius
+    pa, pb = ia[ok], ib[ok]
+    pairing = np.concatenate([pa[:, None], pb[:, None]], axis=-1)
+    return pairing, np.delete(np.arange(setA.shape[0]), pa), np.delete(np.arange(setB.shape[0]), pb)

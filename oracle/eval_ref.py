@@ -90,3 +90,66 @@ def score_pair(prediction, ground_truth):
     if np.max(p) > 0:
         return aji_plus(label_image(g), label_image(p))
     return 0
+
+
+# ---- the other metrics of stats_utils.py (get_fast_aji :16-95, get_fast_pq :183-285, dice :288-362, remap_label :365-395),
+# restated on the pair statistics; pinned by tests/golden/eval_metrics.npz (tools/gen_golden_metrics.py) ------------------
+def _pair_stats(true, pred):
+    t, p = np.asarray(true).astype(np.int64), np.asarray(pred).astype(np.int64)
+    nt, npd = int(t.max()), int(p.max())
+    inter = np.zeros((nt + 1, npd + 1), np.int64)
+    np.add.at(inter, (t.ravel(), p.ravel()), 1)
+    return inter.sum(1), inter.sum(0), inter
+
+
+def fast_aji(true, pred):
+    at, ap, inter = _pair_stats(true, pred)
+    i = inter[1:, 1:].astype(np.float64)
+    u = np.where(i > 0, at[1:, None] + ap[None, 1:] - i, 0.0)
+    iou = i / (u + 1.0e-6)
+    best, val = iou.argmax(1), iou.max(1)
+    rows = np.nonzero(val > 0)[0]
+    cols = best[rows]
+    union = u[rows, cols].sum() + at[1:][np.setdiff1d(np.arange(len(at) - 1), rows)].sum() + \
+        ap[1:][np.setdiff1d(np.arange(len(ap) - 1), cols)].sum()
+    return i[rows, cols].sum() / union
+
+
+def fast_pq(true, pred, match_iou=0.5):
+    from scipy.optimize import linear_sum_assignment
+    at, ap, inter = _pair_stats(true, pred)
+    i = inter[1:, 1:].astype(np.float64)
+    iou = np.where(i > 0, i / (at[1:, None] + ap[None, 1:] - i), 0.0)
+    if match_iou >= 0.5:
+        rows, cols = np.nonzero(iou > match_iou)
+    else:
+        rows, cols = linear_sum_assignment(-iou)
+        keep = iou[rows, cols] > match_iou
+        rows, cols = rows[keep], cols[keep]
+    tp = len(rows)
+    fn, fp = (len(at) - 1) - len(set(rows)), (len(ap) - 1) - len(set(cols))
+    dq = tp / (tp + 0.5 * fp + 0.5 * fn)
+    sq = iou[rows, cols].sum() / (tp + 1.0e-6)
+    return np.array([dq, sq, dq * sq]), rows + 1, cols + 1
+
+
+def dice_2(true, pred):
+    at, ap, inter = _pair_stats(true, pred)
+    i = inter[1:, 1:]
+    return 2 * i.sum() / ((at[1:, None] + ap[None, 1:]) * (i > 0)).sum()
+
+
+def dice_1(true, pred):
+    t, p = np.asarray(true) > 0, np.asarray(pred) > 0
+    return 2.0 * (t & p).sum() / (t.sum() + p.sum())
+
+
+def remap_label(pred, by_size=False):
+    pred = np.asarray(pred)
+    ids = [i for i in np.unique(pred) if i != 0]
+    if by_size:
+        ids = sorted(ids, key=lambda i: -(pred == i).sum())      # stable: equal sizes keep id order
+    out = np.zeros(pred.shape, np.int32)
+    for k, i in enumerate(ids):
+        out[pred == i] = k + 1
+    return out

@@ -146,3 +146,28 @@ def test_eval_worker_end_to_end(tmp_path):
     for i in range(n_img):
         kept = tiffio.imread(str(out_dir / f"mask_{i:03d}.tif"))
         assert np.array_equal(kept, masks[best][i])
+
+
+def test_other_metrics_match_reference():
+    """get_fast_aji / get_fast_pq / get_fast_dice_2 / get_dice_1 / get_dice_2 / remap_label / pair_coordinates of the
+    reference module (stats_utils.py:16-95, 183-437) on the device's pair statistics vs vectors from the real functions."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from src.evaluation import stats_utils as S
+    GM = np.load(ROOT / "tests" / "golden" / "eval_metrics.npz")
+    for c in range(5):
+        gl, pl = G[f"c{c}_gt_lab"], G[f"c{c}_pred_lab"]
+        assert abs(S.get_fast_aji(gl, pl) - float(GM[f"c{c}_aji"])) < 1e-12
+        for tag, thr in (("pq50", 0.5), ("pq30", 0.3)):
+            (dq, sq, pq), (pt, pp, ut, up) = S.get_fast_pq(gl, pl, match_iou=thr)
+            assert np.allclose([dq, sq, pq], GM[f"c{c}_{tag}"], rtol=0, atol=1e-12)
+            assert np.array_equal(np.asarray(pt), GM[f"c{c}_{tag}_pt"]) and np.array_equal(np.asarray(pp), GM[f"c{c}_{tag}_pp"])
+            assert np.array_equal(np.asarray(ut, np.int64), GM[f"c{c}_{tag}_ut"])
+            assert np.array_equal(np.asarray(up, np.int64), GM[f"c{c}_{tag}_up"])
+        assert abs(S.get_fast_dice_2(gl, pl) - float(GM[f"c{c}_dice2"])) < 1e-12
+        assert abs(S.get_dice_2(gl, pl) - float(GM[f"c{c}_dice2_slow"])) < 1e-12
+        assert abs(S.get_dice_1(gl, pl) - float(GM[f"c{c}_dice1"])) < 1e-12
+        assert np.array_equal(S.remap_label(G[f"c{c}_pred"]), GM[f"c{c}_remap"])
+        assert np.array_equal(S.remap_label(G[f"c{c}_pred"], by_size=True), GM[f"c{c}_remap_size"])
+    pairing, ua, ub = S.pair_coordinates(GM["pc_A"], GM["pc_B"], 4.0)
+    assert np.array_equal(pairing, GM["pc_pairing"]) and np.array_equal(ua, GM["pc_ua"]) and np.array_equal(ub, GM["pc_ub"])
