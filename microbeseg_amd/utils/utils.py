@@ -11,6 +11,18 @@ TESTED_IMG_SHAPES = (64, 128, 256, 320, 512, 768, 1024, 1280, 1408, 1600, 1920, 
                      6080, 8192)
 
 
+def plane_gen(img):
+    """generator yielding the planes of a 2-D image (what omero's createImageFromNumpySeq wants; reference utils.py:5-8)"""
+    for p in [img]:
+        yield p
+
+
+def write_inference_results(results, path):
+    """Write inference results (dict) to ``path / 'results.json'`` (reference utils.py:110-121)."""
+    with open(path / 'results.json', 'w', encoding='utf-8') as outfile:
+        json.dump(results, outfile, ensure_ascii=False, indent=2)
+
+
 def get_nucleus_ids(img):
     """ Ids (> 0) present in an intensity-coded label image (reference utils.py:11-22). """
     values = np.unique(img)
