@@ -397,7 +397,10 @@ def _bf(t):
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,two_src", [(2, 64, 64, 16, 32, False), (1, 96, 160, 32, 40, False),
                                                      (2, 128, 64, 16, 16, True), (1, 256, 256, 16, 16, False),
-                                                     (1, 40, 24, 32, 20, False), (3, 64, 128, 30, 64, False)])
+                                                     (1, 40, 24, 32, 20, False), (3, 64, 128, 30, 64, False),
+                                                     # weight tensor > 2 MB: pixel-tile-fastest workgroup order, with
+                                                     # (16 tiles) and without (256 tiles) split-K
+                                                     (2, 512, 512, 16, 16, False), (8, 512, 512, 32, 32, False)])
 def test_bf16_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
     """MSEG_PREC_BF16 launches (BASELINE configs[2]): operands rounded to bf16 (RNE) while staged, fp32 accumulate.
     Reference = torch fp32 convolution of the bf16-rounded operands; what is left is the accumulation order and, for
