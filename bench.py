@@ -44,6 +44,9 @@ def parse():
                          "accumulate / storage / normalisation statistics (the default line is the fp32 configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracketing of MFMA kernels")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a hipGraph (training/graph_step.py; 1 GPU, Adam; implies --no-kernel-timing): "
+                         "for small batches / bf16, where the host cannot enqueue ~600 launches per step fast enough")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary inference (Mpixels/s) measurement")
     ap.add_argument("--infer-size", type=int, default=2048)
     ap.add_argument("--infer-frames", type=int, default=8)
@@ -222,8 +225,13 @@ def main():
     torch.manual_seed(0)
     net = build_unet(args.arch, args.act, "conv", args.norm, dev, world if world > 1 else 1,
                      ch_out=3 if args.arch == "U" else 1, filters=filters)
+    if args.graph:
+        if world > 1 or args.optimizer != "adam":
+            raise SystemExit("--graph: single GPU and Adam only")
+        args.no_kernel_timing = True
     if args.optimizer == "adam":
-        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True,
+                               capturable=args.graph)
     else:
         from microbeseg_amd.training.ranger2020 import Ranger
         opt = Ranger(net.parameters(), lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6)
@@ -231,8 +239,7 @@ def main():
     batches = [synthetic_batch(args.batch, args.size, args.arch, 1234 + 17 * rank + i, dev) for i in range(2)]
     net.train()
 
-    def step(i):
-        img, l1, l2 = batches[i % len(batches)]
+    def one_step(img, l1, l2):
         opt.zero_grad()
         if args.arch == "DU":
             border, cell = net(img)
@@ -242,6 +249,14 @@ def main():
         loss.backward()
         opt.step()
         return loss
+
+    if args.graph:
+        from microbeseg_amd.training.graph_step import GraphedTrainStep
+        one_step = GraphedTrainStep(one_step, opt, warmup=2)
+        args.warmup = max(args.warmup, 3)             # two eager calls + the capture happen before the timed region
+
+    def step(i):
+        return one_step(*batches[i % len(batches)])
 
     def fence():
         if world > 1:
@@ -279,7 +294,8 @@ def main():
                                f"{args.act}/{args.norm}, SmoothL1x2 + Adam(amsgrad)" if args.arch == "DU" else
                                f"{args.arch}-Net boundary training step, filters {list(filters)}, {args.size}px, "
                                f"batch {args.batch}, ce_dice + Adam",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if args.graph else "eager"},
     }
     if fwd_gflop is not None:
         train_tflop_per_crop = 3.0 * fwd_gflop * (args.size / 256.0) ** 2 / 1e3

@@ -1,0 +1,72 @@
+"""hipGraph capture of one training step (forward, loss, backward, optimizer step).
+
+A step of the hot path is ~600 kernel launches; at the GUI's default batch sizes (4, 8) or in bf16 mode the host cannot
+enqueue them as fast as the MI355X executes them.  ``GraphedTrainStep`` records the step once (``torch.cuda.CUDAGraph`` is a
+hipGraph on ROCm) and replays it: the batch is copied into static input tensors, everything else — activations, gradients,
+optimizer state — lives in the graph's private memory pool at fixed addresses.
+
+Rules of the capture (all met by this build's step): no host synchronisation inside the step (losses stay device
+scalars), every kernel on the capturing stream (the C ABI takes the stream from torch), a capturable optimizer
+(``torch.optim.Adam(..., capturable=True)``: step counters on the device).  The learning rate is baked into the graph, so
+``set_lr`` re-records it (ReduceLROnPlateau fires a few times per training).  Single-GPU only: the data-parallel wrapper
+overlaps RCCL all-reduces with the backward pass, which is left to the eager path.
+The first ``warmup`` calls run eagerly (workspaces, lazily built tables and the optimizer state must exist before the
+capture) — with real batches, so the trajectory is the eager one.
+"""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, step_fn, optimizer, warmup=2):
+        """step_fn(*batch) -> loss tensor (device scalar); must run forward, backward and optimizer.step() on the given
+        tensors and call optimizer.zero_grad(set_to_none=True) first."""
+        self.step_fn = step_fn
+        self.optimizer = optimizer
+        self.warmup = warmup
+        self.calls = 0
+        self.graph = None
+        self.static_in = None
+        self.static_loss = None
+        self.shapes = None
+        self.stream = torch.cuda.Stream()            # warm-up and capture run on the same side stream (torch's recipe)
+
+    def _capture(self, batch):
+        self.static_in = [b.clone() if b is not None else None for b in batch]
+        self.shapes = self._signature(batch)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=self.stream):
+            self.static_loss = self.step_fn(*self.static_in)
+        self.graph = g
+
+    @staticmethod
+    def _signature(batch):
+        return [(tuple(b.shape), b.dtype) if b is not None else None for b in batch]
+
+    def invalidate(self):
+        """forget the recorded step (learning rate or any other baked-in scalar changed)"""
+        self.graph = None
+
+    def set_lr(self, lr):
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        self.invalidate()
+
+    def __call__(self, *batch):
+        self.calls += 1
+        if self.calls <= self.warmup:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                loss = self.step_fn(*batch)
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return loss
+        if self.graph is not None and self._signature(batch) != self.shapes:
+            return self.step_fn(*batch)              # e.g. the last, smaller batch of an epoch: eager
+        if self.graph is None:
+            self._capture(batch)
+        else:
+            for s, b in zip(self.static_in, batch):
+                if s is not None:
+                    s.copy_(b, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss

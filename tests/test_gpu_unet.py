@@ -247,3 +247,48 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
         noise = _l2_rel(p16[k].grad, p32[k].grad)                          # what bf16 rounding itself does to this gradient
         assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(2e-2, noise), k
         assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(4e-2, 2 * noise), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_train_step_equals_eager(precision, dev, request):
+    """hipGraph replay of the training step (training/graph_step.py): same losses and bit-identical weights as the eager
+    step on the same batches (the kernels and their order are the same; only the launches are pre-recorded)."""
+    from microbeseg_amd import engine
+    from microbeseg_amd.training.graph_step import GraphedTrainStep
+    from microbeseg_amd.training.losses import get_loss
+    from microbeseg_amd.utils.unets import build_unet
+    request.addfinalizer(lambda: engine.set_precision("fp32"))
+    engine.set_precision(precision)
+    crit = get_loss("smooth_l1", "distance")
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.rand(4, 1, 64, 64, generator=g) * 2 - 1, torch.rand(4, 1, 64, 64, generator=g),
+                torch.rand(4, 1, 64, 64, generator=g)) for _ in range(7)]
+    batches = [tuple(t.to(dev) for t in b) for b in batches]
+    odd = tuple(t[:3].contiguous() for t in batches[0])        # a smaller batch in between: falls back to eager
+
+    def run(graphed):
+        torch.manual_seed(11)
+        net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=(64, 128))
+        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True, capturable=True)
+        net.train()
+
+        def step(x, lb, lc):
+            opt.zero_grad(set_to_none=True)
+            border, cell = net(x)
+            loss = crit["border"](border, lb) + crit["cell"](cell, lc)
+            loss.backward()
+            opt.step()
+            return loss
+        fn = GraphedTrainStep(step, opt, warmup=2) if graphed else step
+        losses = []
+        for i, b in enumerate(batches):
+            losses.append(float(fn(*b).detach()))
+            if i == 4:
+                losses.append(float(fn(*odd).detach()))
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    l_e, sd_e = run(False)
+    l_g, sd_g = run(True)
+    assert l_e == l_g
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
