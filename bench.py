@@ -49,8 +49,34 @@ def parse():
                          "for small batches / bf16, where the host cannot enqueue ~600 launches per step fast enough")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary inference (Mpixels/s) measurement")
     ap.add_argument("--infer-size", type=int, default=2048)
-    ap.add_argument("--infer-frames", type=int, default=8)
+    ap.add_argument("--infer-frames", type=int, default=16, help="T of the 2D+t stack (SURVEY.md §8d: T = 16)")
+    ap.add_argument("--no-bf16-block", action="store_true",
+                    help="skip the secondary BASELINE configs[2] measurement (320x320, bf16) of the default run")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0 = pick)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU rehearsal of the multi-rank contract (gloo, no kernels): launcher, rendezvous, barrier + "
+                         "max-over-ranks timing and the JSON line, with a sleep as the step; `value` is meaningless")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a rank environment: start the N ranks ourselves, one process per GPU, as
+    fresh children of a process that has not touched the GPU (never re-exec after HIP is initialised), exactly the
+    way the driver does it: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>.
+    Rank 0's JSON line goes to our stdout; our exit code is the launcher's."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synthetic_batch(batch, size, arch, seed, device):
@@ -181,41 +207,75 @@ def inference_metric(args, net, dev):
                              "sample": "1 frame through oracle/postproc_ref.c (single thread, like scipy/skimage)"}}
 
 
-def default_workload(args):
-    return (args.batch, args.size, args.arch, args.act, args.norm, tuple(args.filters), args.optimizer,
-            args.precision) == (32, 256, "DU", "relu", "bn", (64, 1024), "adam", "fp32")
+def workload_key(args):
+    return {"batch": args.batch, "size": args.size, "arch": args.arch, "act": args.act, "norm": args.norm,
+            "filters": list(args.filters), "optimizer": args.optimizer, "precision": args.precision}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed TCC-counter profile of this same command
-    (tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied).
-    bench.py cannot collect PMC counters itself; the profile is part of the repo, not of the reference."""
+# profiles written before the traffic files carried their own `__config__` (tools/pmc_traffic.sh now stores it)
+_LEGACY_PROFILE_CONFIG = {
+    "r01f": {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn", "filters": [64, 1024],
+             "optimizer": "adam", "precision": "fp32"},
+    "r01g": {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn", "filters": [64, 1024],
+             "optimizer": "adam", "precision": "fp32"},
+    "r01h_bf16_320": {"batch": 32, "size": 320, "arch": "DU", "act": "relu", "norm": "bn", "filters": [64, 1024],
+                      "optimizer": "adam", "precision": "bf16"},
+}
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the newest committed TCC-counter profile OF THIS WORKLOAD
+    (tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied; the
+    profile records the bench configuration it was taken on and only a profile of the same batch / size / net /
+    precision is used).  bench.py cannot collect PMC counters itself; the profile is part of the repo."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_pmc.json")))
-    if not files:
-        return {}
-    tab = json.load(open(files[-1]))
-    ent = tab.get(kernel)
-    if ent is None:
-        return {}
-    return {"traffic": int(ent["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (avg)",
-            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    want = workload_key(args)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")), reverse=True)
+    for f in files:
+        tab = json.load(open(f))
+        cfg = tab.get("__config__")
+        if cfg is None:
+            cfg = _LEGACY_PROFILE_CONFIG.get(os.path.basename(f)[:-len("_hbm_traffic_pmc.json")])
+        if cfg != want:
+            continue
+        ent = tab.get(kernel)
+        if ent is None:
+            continue
+        return {"traffic": int(ent["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (avg)",
+                "traffic_source": "profiles/" + os.path.basename(f)}
+    return {"traffic": None, "traffic_source": "none"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+def rehearse(args, world, rank):
+    """CPU rehearsal (gloo): everything of the N-rank contract except the kernels."""
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "training crops/sec (256px)", "value": 0.0, "unit": "crops/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "rehearsal": True,
+                          "data": "none", "config": {"workload": "launcher rehearsal on CPU (gloo), no kernels",
+                                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"}}),
+              flush=True)
 
+
+def train_metric(args, dev, world, rank, timing=True):
+    """W untimed + K timed training steps of the workload `args` names; returns (JSON dict, net)."""
+    import torch.distributed as dist
     from microbeseg_amd import engine
     from microbeseg_amd.utils.unets import build_unet
     from microbeseg_amd.training.losses import get_loss
@@ -225,13 +285,14 @@ def main():
     torch.manual_seed(0)
     net = build_unet(args.arch, args.act, "conv", args.norm, dev, world if world > 1 else 1,
                      ch_out=3 if args.arch == "U" else 1, filters=filters)
-    if args.graph:
+    graph = args.graph
+    if graph:
         if world > 1 or args.optimizer != "adam":
             raise SystemExit("--graph: single GPU and Adam only")
-        args.no_kernel_timing = True
+        timing = False
     if args.optimizer == "adam":
-        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True,
-                               capturable=args.graph)
+        from microbeseg_amd.training.optim import make_adam
+        opt = make_adam(net.parameters(), capturable=graph)
     else:
         from microbeseg_amd.training.ranger2020 import Ranger
         opt = Ranger(net.parameters(), lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6)
@@ -250,10 +311,11 @@ def main():
         opt.step()
         return loss
 
-    if args.graph:
+    warmup = args.warmup
+    if graph:
         from microbeseg_amd.training.graph_step import GraphedTrainStep
         one_step = GraphedTrainStep(one_step, opt, warmup=2)
-        args.warmup = max(args.warmup, 3)             # two eager calls + the capture happen before the timed region
+        warmup = max(warmup, 3)             # two eager calls + the capture happen before the timed region
 
     def step(i):
         return one_step(*batches[i % len(batches)])
@@ -263,9 +325,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    prof = None if args.no_kernel_timing else engine.KernelTimer()
+    prof = engine.KernelTimer() if timing else None
     engine.set_kernel_timer(prof)
     fence()
     t0 = time.perf_counter()
@@ -282,21 +344,29 @@ def main():
     crops = args.batch * world * args.steps
     value = crops / dt
     fwd_gflop = FWD_GFLOP_256.get((args.arch, filters))
+    cfg_no = 1 if args.precision == "fp32" else 2
+    if world > 1:
+        cfg_no = 3
+    prec_txt = "fp32" if args.precision == "fp32" else \
+        "bf16 forward/backward (bf16 matrix-core operands, fp32 accumulate and norm statistics)"
+    if args.arch == "DU":
+        wl = (f"BASELINE configs[{cfg_no}]: {args.arch}-Net distance-map training step, filters {list(filters)}, "
+              f"{args.size}x{args.size} crops, per-GPU batch {args.batch}, {prec_txt}, {args.act}/{args.norm}, "
+              f"SmoothL1x2 + Adam(amsgrad)")
+    else:
+        wl = (f"{args.arch}-Net boundary training step, filters {list(filters)}, {args.size}px, batch {args.batch}, "
+              f"{prec_txt}, ce_dice + Adam")
     out = {
         "metric": "training crops/sec (256px)" if args.size == 256 else f"training crops/sec ({args.size}px)",
-        "value": round(value, 3), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{1 if args.precision == 'fp32' else 2}]: {args.arch}-Net "
-                               f"distance-map training step, filters "
-                               f"{list(filters)}, {args.size}x{args.size} crops, per-GPU batch {args.batch}, "
-                               f"{'fp32' if args.precision == 'fp32' else 'bf16 3x3 convolutions (fp32 accumulate, fp32 storage and norm statistics)'}, "
-                               f"{args.act}/{args.norm}, SmoothL1x2 + Adam(amsgrad)" if args.arch == "DU" else
-                               f"{args.arch}-Net boundary training step, filters {list(filters)}, {args.size}px, "
-                               f"batch {args.batch}, ce_dice + Adam",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if args.graph else "eager"},
+        "config": {"workload": wl, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if graph else "eager"},
+        "per_gpu_value": round(value / world, 3),
     }
+    if world > 1:
+        out["config"]["collective"] = "RCCL all-reduce of fp32 gradient buckets, overlapped with the backward"
     if fwd_gflop is not None:
         train_tflop_per_crop = 3.0 * fwd_gflop * (args.size / 256.0) ** 2 / 1e3
         out["model_tflops_per_gpu"] = round(value / world * train_tflop_per_crop, 2)
@@ -313,19 +383,59 @@ def main():
                                "peak": peak, "unit": "TFLOP/s",
                                "frac": round(dom["tflops"] / peak, 4), "traffic": None,
                                "avg_launch_ms": round(dom["avg_ms"], 4), "launches": dom["launches"]}
-            if default_workload(args):
-                out["roofline"].update(pmc_traffic(dom["kernel"]))
+            out["roofline"].update(pmc_traffic(dom["kernel"], args))
             out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "total_ms_per_step": round(v["total_ms"] / args.steps, 3),
                                   "avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] // args.steps}
                               for k, v in kernels.items()}
+    del opt, batches
+    for p_ in net.parameters():
+        p_.grad = None
+    return out, net
+
+
+def main():
+    args = parse()
+    in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank_env:
+        sys.exit(launch_ranks(args))          # nothing has touched the GPU in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.rehearse:
+        return rehearse(args, world, rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from microbeseg_amd import engine
+    out, net = train_metric(args, dev, world, rank, timing=not args.no_kernel_timing)
+    headline = workload_key(args) == {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn",
+                                      "filters": [64, 1024], "optimizer": "adam", "precision": "fp32"}
     if rank == 0 and world == 1 and not args.no_inference and args.arch == "DU":
-        del opt
-        for p_ in net.parameters():
-            p_.grad = None
         torch.cuda.empty_cache()
         out["inference"] = inference_metric(args, net, dev)
+    del net
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and headline and not args.no_bf16_block:
+        # BASELINE configs[2] next to the fp32 headline, so that the driver's default run records it too
+        import copy
+        a2 = copy.copy(args)
+        a2.precision, a2.size, a2.graph = "bf16", 320, False
+        a2.steps, a2.warmup = max(args.steps, 10), max(args.warmup, 3)
+        blk, net2 = train_metric(a2, dev, 1, 0, timing=not args.no_kernel_timing)
+        del net2
+        torch.cuda.empty_cache()
+        engine.set_precision(args.precision)
+        out["bf16_320"] = blk
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, filters)
+        out["cpu_baseline"] = cpu_baseline(args, tuple(args.filters))
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -136,6 +136,20 @@ int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, int W, int 
 int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C, int Cpad, int st, int sr, int sc,
                      void* stream);
 
+/* Every repack of a network in one launch, after an optimizer step (replaces the per-layer repacks of the conv
+ * weights the forward / data-gradient kernels consume: unets.py:112,137,192,244 hold them in torch's layout).
+ * `jobs_dev`: njobs records in DEVICE memory, sorted by first_block; job j owns blocks [first_block[j],
+ * first_block[j+1]) of 1024 destination elements each, total_blocks in all.  dst / dst16 (bf16 operand) may be NULL. */
+typedef struct MsegPackJob {
+  const float* src;
+  float* dst;
+  uint16_t* dst16;
+  int32_t T, R, Rpad, C, Cpad, st, sr, sc;
+  uint32_t first_block;
+  uint32_t reserved;
+} MsegPackJob;
+int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned total_blocks, void* stream);
+
 /* ---- normalisation (BatchNorm2d / GroupNorm(8) / InstanceNorm2d applied AFTER the activation) --------------
  * forward statistics of a = act(z) over an NHWC tensor, fp64 accumulation:
  *   mseg_norm_stats: fills scale/shift ([N][C], ss = C for GN/IN; [C], ss = 0 for BN) such that
@@ -199,6 +213,8 @@ int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, 
                      double total_px, double dice_weight, const float* gscale_dev, float* grad, void* stream);
 
 /* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
+/* torch.optim.Adam(amsgrad=True, weight_decay=0) on ONE flat range (train.py:380-385): p, g, exp_avg, exp_avg_sq,
+ * max_exp_avg_sq of n elements; `step` = 1-based step count (bias corrections are evaluated on the host in fp64). */
 int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
                            float beta1, float beta2, float eps, int step, void* stream);
 /* One Ranger update of one parameter tensor (ranger2020.py:142-206): gradient centralisation over dims 1.. (do_gc, rows =

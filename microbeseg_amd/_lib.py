@@ -46,6 +46,13 @@ class MsegWgrad(C.Structure):
                 ("splits", C.c_int32), ("phase", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MsegPackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst16", C.c_void_p),
+                ("T", C.c_int32), ("R", C.c_int32), ("Rpad", C.c_int32), ("C", C.c_int32), ("Cpad", C.c_int32),
+                ("st", C.c_int32), ("sr", C.c_int32), ("sc", C.c_int32),
+                ("first_block", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -62,6 +69,7 @@ SIGNATURES = {
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mseg_activation": (_I, [_P, _I, _I, _I, _I, _P, _P]),

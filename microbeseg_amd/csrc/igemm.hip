@@ -1829,3 +1829,39 @@ extern "C" int mseg_pack_weight(const float* src, float* dst, int T, int R, int 
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
+
+// ---- all weight repacks of a network in ONE launch (called by the optimizer after it has updated the weights) ----------
+// jobs[] lives in device memory (uploaded once: weights are views of the optimizer's flat arena and the packed operands are
+// persistent buffers, so the pointers never change); block b serves job j with first_block[j] <= b < first_block[j+1],
+// 1024 destination elements per block.  dst (fp32 operand) and dst16 (bf16 operand of the MSEG_PREC_BF16 kernels) are
+// both optional.
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const MsegPackJob* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  const unsigned b = blockIdx.x;
+  while (lo < hi) {                                  // last job whose first_block <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const MsegPackJob j = jobs[lo];
+  const size_t total = (size_t)j.T * j.Rpad * j.Cpad;
+  const size_t base = (size_t)(b - j.first_block) * 1024u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = base + (size_t)k * 256u + threadIdx.x;
+    if (i >= total) break;
+    const int c = (int)(i % (unsigned)j.Cpad);
+    const size_t tr = i / (unsigned)j.Cpad;
+    const int r = (int)(tr % (unsigned)j.Rpad);
+    const int t = (int)(tr / (unsigned)j.Rpad);
+    const float v = (c < j.C && r < j.R) ? j.src[(size_t)t * j.st + (size_t)r * j.sr + (size_t)c * j.sc] : 0.f;
+    if (j.dst) j.dst[i] = v;
+    if (j.dst16) ((__bf16*)j.dst16)[i] = (__bf16)v;
+  }
+}
+
+extern "C" int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned total_blocks, void* stream) {
+  if (!jobs_dev || njobs <= 0 || total_blocks == 0) return MSEG_EINVAL;
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}

@@ -200,18 +200,44 @@ extern "C" int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int 
 }
 
 // ---- Adam (amsgrad) — torch.optim.Adam(lr 8e-4, betas (0.9, 0.999), eps 1e-8, amsgrad=True): train.py:380-385 ----
-__global__ void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                    float* __restrict__ v, float* __restrict__ vmax, size_t n, float lr, float beta1,
-                                    float beta2, float eps, float bc1, float bc2_sqrt) {
+// ONE launch over the flat parameter arena of training/optim.py (FusedAdam): every parameter tensor of the network is a
+// view of one fp32 buffer (likewise gradients and the three state tensors), so the update is a single HBM-bound stream:
+// reads p, g, m, v, vmax and writes p, m, v, vmax = 36 B / parameter (1.67 GB for the default DU-Net).
+__device__ __forceinline__ void adam_amsgrad_one(float& p, float g, float& m, float& v, float& vmax, float w1, float beta2,
+                                                 float w2, float eps, float step_size, float bc2_sqrt) {
+  m = m + (g - m) * w1;                           // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * beta2 + w2 * g * g;                     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+  vmax = fmaxf(vmax, v);                          // torch.maximum(max_exp_avg_sq, exp_avg_sq)
+  const float denom = sqrtf(vmax) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);                // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           float* __restrict__ vmax, size_t n, float lr, float beta1,
+                                                           float beta2, float eps, float bc1, float bc2_sqrt) {
   const float step_size = lr / bc1;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
-    const float vm = fmaxf(vmax[i], vi);
-    m[i] = mi; v[i] = vi; vmax[i] = vm;
-    const float denom = sqrtf(vm) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)vmax)) & 15) == 0;
+  size_t tail = 0;
+  if (aligned) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i], vx = ((float4*)vmax)[i];
+      const float4 gg = ((const float4*)g)[i];
+      adam_amsgrad_one(pp.x, gg.x, mm.x, vv.x, vx.x, w1, beta2, w2, eps, step_size, bc2_sqrt);
+      adam_amsgrad_one(pp.y, gg.y, mm.y, vv.y, vx.y, w1, beta2, w2, eps, step_size, bc2_sqrt);
+      adam_amsgrad_one(pp.z, gg.z, mm.z, vv.z, vx.z, w1, beta2, w2, eps, step_size, bc2_sqrt);
+      adam_amsgrad_one(pp.w, gg.w, mm.w, vv.w, vx.w, w1, beta2, w2, eps, step_size, bc2_sqrt);
+      ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv; ((float4*)vmax)[i] = vx;
+    }
+    tail = n4 << 2;
+  }
+  for (size_t i = tail + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pp = p[i], mm = m[i], vv = v[i], vx = vmax[i];
+    adam_amsgrad_one(pp, g[i], mm, vv, vx, w1, beta2, w2, eps, step_size, bc2_sqrt);
+    p[i] = pp; m[i] = mm; v[i] = vv; vmax[i] = vx;
   }
 }
 
@@ -220,7 +246,10 @@ extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float*
   if (!p || !g || !m || !v || !vmax || n == 0 || step < 1) return MSEG_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(loss_blocks(n) * 2), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256u * 16u) blocks = 256u * 16u;      // 16 workgroups of 4 waves per CU, grid-stride
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
                      n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;

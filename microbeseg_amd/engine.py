@@ -229,37 +229,109 @@ _splitk_ws = {}      # device -> grow-only scratch of the split-K igemm launches
 
 
 class PackedW:
-    """GEMM operand [T][Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero filled) produced by pack_weight."""
-    __slots__ = ("t", "Npad", "Kpad", "_t16")
+    """GEMM operand [T][Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero filled) of one conv weight, kept in a
+    PERSISTENT buffer next to the parameter it was packed from (`param._mseg_packs[kind]`) and refreshed only when the
+    parameter has changed: torch's version counter of the parameter (every in-place update of an optimizer,
+    load_state_dict, ... bumps it) and its data pointer are recorded at pack time.  Inference never repacks; a training
+    step repacks each operand once — per layer on first use, or, with training/optim.FusedAdam, all operands of the
+    network in ONE launch right after the update (`repack_all`)."""
+    __slots__ = ("param", "job", "merge", "t", "Npad", "Kpad", "_t16", "version", "src_ptr")
 
-    def __init__(self, t, Npad, Kpad):
-        self.t, self.Npad, self.Kpad = t, Npad, Kpad
+    def __init__(self, param, T, R, Cc, st, sr, sc, merge_taps):
+        self.param = param
+        self.merge = merge_taps
+        self.Kpad = _round_up(Cc, 32)
+        if merge_taps:      # the T blocks of R rows back to back (one GEMM with N = T*R), padded as a whole
+            self.Npad = _round_up(T * R, 128)
+            rpad = R
+            self.t = torch.zeros(self.Npad * self.Kpad, dtype=torch.float32, device=param.device)
+        else:
+            self.Npad = rpad = _round_up(R, 128)
+            self.t = torch.empty(T * self.Npad * self.Kpad, dtype=torch.float32, device=param.device)
+        self.job = (T, R, rpad, Cc, self.Kpad, st, sr, sc)
         self._t16 = None
+        self.version, self.src_ptr = -1, 0
+
+    def stale(self):
+        return self.version != self.param._version or self.src_ptr != self.param.data_ptr()
+
+    def mark_fresh(self):
+        self.version, self.src_ptr = self.param._version, self.param.data_ptr()
+
+    def refresh(self):
+        lib = _lib.load()
+        T, R, rpad, Cc, kpad, st, sr, sc = self.job
+        src = self.param.detach()
+        check(lib.mseg_pack_weight(src.data_ptr(), self.t.data_ptr(), T, R, rpad, Cc, kpad, st, sr, sc, _stream()),
+              "pack_weight")
+        if self._t16 is not None:
+            check(lib.mseg_f32_to_bf16(self.t.data_ptr(), self._t16.data_ptr(), self.t.numel(), _stream()), "f32_to_bf16")
+        self.mark_fresh()
 
     def bf16(self):
-        """the same operand rounded to bf16 (operand of a MSEG_PREC_BF16 launch), converted on first use"""
+        """the same operand rounded to bf16 (operand of a MSEG_PREC_BF16 launch); created on first use, then kept
+        in step with the fp32 operand by refresh() / repack_all()"""
         if self._t16 is None:
-            self._t16 = torch.empty(self.t.numel(), dtype=torch.bfloat16, device=self.t.device)
+            if self.merge:
+                self._t16 = torch.zeros(self.t.numel(), dtype=torch.bfloat16, device=self.t.device)
+            else:
+                self._t16 = torch.empty(self.t.numel(), dtype=torch.bfloat16, device=self.t.device)
             check(_lib.load().mseg_f32_to_bf16(self.t.data_ptr(), self._t16.data_ptr(), self.t.numel(), _stream()),
                   "f32_to_bf16")
         return self._t16
 
 
-def pack_weight(src, T, R, Cc, st, sr, sc, merge_taps=False):
-    """dst[(t*Rpad + r)*Kpad + c] = src[t*st + r*sr + c*sc], zero padded.  merge_taps: the T blocks of R rows are
-    laid out back to back (one GEMM with N = T*R: ConvTranspose2d as a 1x1 GEMM) and padded as a whole."""
-    lib = _lib.load()
-    kpad = _round_up(Cc, 32)
-    if merge_taps:
-        npad = _round_up(T * R, 128)
-        dst = torch.zeros(npad * kpad, dtype=torch.float32, device=src.device)
-        rpad = R
-    else:
-        npad = rpad = _round_up(R, 128)
-        dst = torch.empty(T * npad * kpad, dtype=torch.float32, device=src.device)
-    check(lib.mseg_pack_weight(src.data_ptr(), dst.data_ptr(), T, R, rpad, Cc, kpad, st, sr, sc, _stream()),
-          "pack_weight")
-    return PackedW(dst, npad, kpad)
+def pack_weight(param, T, R, Cc, st, sr, sc, merge_taps=False, kind=None):
+    """dst[(t*Rpad + r)*Kpad + c] = param[t*st + r*sr + c*sc], zero padded.  With `kind` ('fwd' / 'dgrad') the operand is
+    cached on the parameter and only refreshed when the parameter has changed; without it a one-off operand is built."""
+    if kind is None:
+        e = PackedW(param, T, R, Cc, st, sr, sc, merge_taps)
+        e.refresh()
+        return e
+    packs = param.__dict__.get("_mseg_packs")
+    if packs is None:
+        packs = param.__dict__["_mseg_packs"] = {}
+    e = packs.get(kind)
+    if e is None:
+        e = packs[kind] = PackedW(param, T, R, Cc, st, sr, sc, merge_taps)
+    if e.stale():
+        e.refresh()
+    return e
+
+
+_pack_tables = {}    # tuple of job keys -> (device table, njobs, total blocks, keep-alive)
+
+
+def repack_all(params):
+    """Refresh every packed operand of `params` in one launch (mseg_pack_weights_multi).  Called by FusedAdam.step()
+    after the update kernel; operands that do not exist yet (first step) are packed lazily by their first consumer."""
+    entries = []
+    for p in params:
+        packs = p.__dict__.get("_mseg_packs")
+        if packs:
+            entries += [e for _, e in sorted(packs.items())]
+    if not entries:
+        return 0
+    key = tuple((id(e), e.param.data_ptr(), e.t.data_ptr(), 0 if e._t16 is None else e._t16.data_ptr()) for e in entries)
+    tab = _pack_tables.get(key)
+    if tab is None:
+        _pack_tables.clear()                        # one live network per process is the common case
+        jobs = (_lib.MsegPackJob * len(entries))()
+        nblk = 0
+        for j, e in zip(jobs, entries):
+            T, R, rpad, Cc, kpad, st, sr, sc = e.job
+            j.src, j.dst = e.param.data_ptr(), e.t.data_ptr()
+            j.dst16 = None if e._t16 is None else e._t16.data_ptr()
+            j.T, j.R, j.Rpad, j.C, j.Cpad, j.st, j.sr, j.sc = T, R, rpad, Cc, kpad, st, sr, sc
+            j.first_block = nblk
+            nblk += (T * rpad * kpad + 1023) // 1024
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        tab = (raw.to(entries[0].t.device), len(entries), nblk)
+        _pack_tables[key] = tab
+    check(_lib.load().mseg_pack_weights_multi(tab[0].data_ptr(), tab[1], tab[2], _stream()), "pack_weights_multi")
+    for e in entries:
+        e.mark_fresh()
+    return len(entries)
 
 
 def _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, morder):
@@ -514,7 +586,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
     if spec.kind == "up":
         cin, cout = wt.shape[0], wt.shape[1]
         assert cin == cin_total
-        wp = pack_weight(wt, 4, cout, cin, 1, 4, cout * 4, merge_taps=True)
+        wp = pack_weight(conv.weight, 4, cout, cin, 1, 4, cout * 4, merge_taps=True, kind="fwd")
         Ho, Wo = 2 * Hi, 2 * Wi
         z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
         igemm(srcs, wp, bias, N, Hi, Wi, Hi, Wi, 1, 1, 1, 0, MODE_CONV, 4 * cout, z, cout,
@@ -534,7 +606,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
             check(_lib.load().mseg_first_conv_fwd(n0.z.data_ptr(), wt.contiguous().data_ptr(), bias.data_ptr(), N, Hi,
                                                   Wi, cin, cout, z.data_ptr(), _stream()), "first_conv_fwd")
         else:
-            wp = pack_weight(wt, 9, cout, cin, 1, cin * 9, 9)
+            wp = pack_weight(conv.weight, 9, cout, cin, 1, cin * 9, 9, kind="fwd")
             igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
         act = spec.act
     node = Node(z, N, Ho, Wo, cout)
@@ -632,10 +704,25 @@ def _accumulate_target(node, shape_like):
     return node.grad, 1
 
 
-def backward(spec, tape, grad_outs, ws, on_grads=None):
+def _grad_buf(param, direct):
+    """Where the gradient of `param` is written.  A parameter owned by training/optim.FusedAdam carries a persistent
+    `.grad` view of the optimizer's gradient arena: the kernels write into it directly, once per zero_grad() (`direct`
+    collects those parameters; autograd then gets None for them, i.e. it neither copies nor accumulates).  Otherwise a
+    fresh tensor that autograd accumulates into `.grad` as usual."""
+    d = param.__dict__
+    if d.get("_mseg_grad_direct") and d.get("_mseg_grad_fresh") and param.grad is not None:
+        d["_mseg_grad_fresh"] = False
+        direct.add(id(param))
+        return param.grad
+    return torch.empty_like(param)
+
+
+def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
     """grad_outs: list of NCHW gradients (None allowed) matching the forward outputs.  Returns {id(param): grad}."""
     lib = _lib.load()
     grads = {}
+    if direct is None:
+        direct = set()
     # heads
     for (head, node), go in zip(tape.heads, grad_outs):
         hc = head.conv
@@ -644,8 +731,8 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
             go = torch.zeros((node.N, co, node.H, node.W), dtype=torch.float32, device=node.z.device)
         go = go.contiguous()
         gy = torch.empty_like(node.z)
-        dW = torch.empty_like(hc.weight)
-        db = torch.empty_like(hc.bias)
+        dW = _grad_buf(hc.weight, direct)
+        db = _grad_buf(hc.bias, direct)
         w = ws.get("head", lib.mseg_head_bwd_workspace_bytes(node.N, node.H * node.W, node.C, co))
         s = node.src()
         check(lib.mseg_head_bwd(C.byref(s), node.N, node.H * node.W, hc.weight.detach().data_ptr(), co,
@@ -674,16 +761,16 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
         conv = sp.conv
         nm = sp.norm_mod
         has_affine = sp.norm in (NORM["bn"], NORM["gn"])
-        dgamma = torch.empty_like(nm.weight) if has_affine else None
-        dbeta = torch.empty_like(nm.bias) if has_affine else None
-        dbias = torch.empty_like(conv.bias)
+        dgamma = _grad_buf(nm.weight, direct) if has_affine else None
+        dbeta = _grad_buf(nm.bias, direct) if has_affine else None
+        dbias = _grad_buf(conv.bias, direct)
         dz = norm_bwd(node, gy, nm.weight.detach() if has_affine else None, dgamma, dbeta, dbias, ws)
         if has_affine:
             grads[id(nm.weight)] = dgamma
             grads[id(nm.bias)] = dbeta
         grads[id(conv.bias)] = dbias
         wt = conv.weight.detach()
-        dW = torch.empty_like(wt)
+        dW = _grad_buf(conv.weight, direct)
         ins = node.inputs
         i0 = ins[0]
         N = node.N
@@ -692,7 +779,7 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
             # dW[ci][co][a][b] = sum x[p][ci] * dz[2p+(a,b)][co]
             wgrad(i0.src(), [plain_src(dz, cout)], dW, N, i0.H, i0.W, node.H, node.W, 2, 2, 2, 0, ws)
             # dx[p][ci] = sum_{ab,co} dz[2p+(a,b)][co] * W[ci][co][a][b]
-            wp = pack_weight(wt, 4, cin, cout, 1, cout * 4, 4)
+            wp = pack_weight(conv.weight, 4, cin, cout, 1, cout * 4, 4, kind="dgrad")
             tgt, acc = _accumulate_target(i0, None)
             igemm([plain_src(dz, cout)], wp, None, N, node.H, node.W, i0.H, i0.W, 2, 2, 2, 0, MODE_CONV, cin,
                   tgt, cin, acc0=acc)
@@ -708,7 +795,7 @@ def backward(spec, tape, grad_outs, ws, on_grads=None):
                 wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride,
                       1, ws, nch_store=cin if is_first else None)
             if not is_first:
-                wp = pack_weight(wt, 9, cin, cout, 1, 9, cin * 9)
+                wp = pack_weight(conv.weight, 9, cin, cout, 1, 9, cin * 9, kind="dgrad")
                 morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
                 if len(ins) == 1:
                     tgt, acc = _accumulate_target(i0, None)
@@ -748,12 +835,13 @@ class _NetFunction(torch.autograd.Function):
         ctx.tape = None
         factory = getattr(module, "_grad_sync_factory", None)
         sync = factory() if factory is not None else None
+        direct = set()
         grads = backward(module._spec, tape, list(grad_outs), module._workspace(tape.nodes[0].z.device),
-                         on_grads=sync.add if sync is not None else None)
+                         on_grads=sync.add if sync is not None else None, direct=direct)
         if sync is not None:
             sync.finish()               # averaged in place (RCCL all-reduce overlapped with the kernels above)
         plist = module._spec.params()
-        return (None, None) + tuple(grads.get(id(p)) for p in plist)
+        return (None, None) + tuple(None if id(p) in direct else grads.get(id(p)) for p in plist)
 
 
 def run_module(module, x):

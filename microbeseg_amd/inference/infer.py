@@ -20,6 +20,16 @@ from ..utils.utils import zero_pad_model_input
 from . import postprocessing as pp
 
 
+def is_out_of_memory(err):
+    """The reference turns EVERY RuntimeError of ``self.net(img_batch)`` into an all-zero mask (infer.py:351-356: "maybe
+    not enough ram/vram?").  Here only a real allocation failure of the network forward gets that treatment; a kernel
+    launch error of libmseg_hip, an asynchronous HIP fault or a shape bug propagates instead of silently writing empty
+    segmentations."""
+    msg = str(err).lower()
+    return isinstance(err, (RuntimeError, MemoryError)) and (
+        "out of memory" in msg or "hiperroroutofmemory" in msg or "hip error: out of memory" in msg)
+
+
 def load_model(model, device):
     """``model``: path of the checkpoint without/with suffix; reads ``<model>.json`` (architecture, label_type) and
     ``<model>.pth`` (state dict), like infer.py:83-84,119-131.  Returns (net in eval mode, model_settings)."""
@@ -87,33 +97,41 @@ class InferWorker(QObject):
         # 2 * (f32(img) - min) / (max - min) - 1, same operation order and scalar types as infer.py:346-348
         img_batch = 2 * (img.astype(np.float32) - min_val) / (max_val - min_val) - 1
         img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
-        img_batch = img_batch.to(self.device)
-        try:
-            with torch.no_grad():   # the reference disables autograd globally (infer.py:343); here only for the call
-                return self._predict(img_batch, pads)
-        except RuntimeError:   # load-bearing in the reference: zero mask instead of a crash (infer.py:354-356)
-            self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
-            return np.zeros_like(img, dtype=np.uint16)[pads[0]:, pads[1]:]
+        with torch.no_grad():   # the reference disables autograd globally (infer.py:343); here only for the call
+            pred = self._forward(img_batch)
+            if pred is None:        # zero mask instead of a crash (infer.py:354-356) — out-of-memory only
+                return np.zeros_like(img, dtype=np.uint16)[pads[0]:, pads[1]:]
+            return self._postprocess(pred, pads).cpu().numpy().view(np.uint16)
 
-    def _predict(self, img_batch, pads):
+    def _forward(self, img_batch):
+        """network forward of one padded frame; None (after the reference's message) if it does not fit in memory"""
+        try:
+            with engine.precision_scope(self.precision):
+                return self.net(img_batch.to(self.device))
+        except (RuntimeError, MemoryError) as err:
+            if not is_out_of_memory(err):
+                raise
+            self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
+            return None
+
+    def _postprocess(self, pred, pads):
+        """prediction (device) -> uint16 labels of the un-padded frame (device tensor, int16 storage)"""
         lib = _lib.load()
         if self.model_settings['label_type'] == 'distance':
-            with engine.precision_scope(self.precision):
-                border, cell = self.net(img_batch)
+            border, cell = pred
             cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
             border = border[0, 0, pads[0]:, pads[1]:].contiguous()
             # every reference caller hands (H, W, 1) arrays to distance_postprocessing -> column-major instance ids
             labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1], th_cell=self.ths[0],
                                                              col_major_ids=True)
         else:
-            with engine.precision_scope(self.precision):
-                logits = self.net(img_batch).contiguous()
+            logits = pred.contiguous()
             _, _, hp, wp = logits.shape
             probs = torch.empty((hp - pads[0], wp - pads[1], 3), dtype=torch.float32, device=logits.device)
             _lib.check(lib.mseg_softmax3_hwc(logits.data_ptr(), hp, wp, int(pads[0]), int(pads[1]), probs.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream), "softmax3_hwc")
             labels, _, _ = pp.boundary_postprocessing_device(probs)
-        return labels.cpu().numpy().view(np.uint16)
+        return labels
 
     def infer_stack(self, img):
         """[T, H, W] stack -> [T, H, W] uint16 masks; per frame min/max + top/left padding exactly like
@@ -157,10 +175,11 @@ class InferWorker(QObject):
                 img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
                 img_batch = 2 * (img_frame.astype(np.float32) - frame_min) / (frame_max - frame_min) - 1
                 img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
-                try:
-                    img_batch = img_batch.to(self.device)
-                    with engine.precision_scope(self.precision):
-                        border, cell = self.net(img_batch)
+                pred = self._forward(img_batch)
+                if pred is None:                 # out of memory: zero mask, like inference() (infer.py:354-356)
+                    pending.append((frame, None, None))
+                else:
+                    border, cell = pred
                     cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
                     border = border[0, 0, pads[0]:, pads[1]:].contiguous()
                     ready = torch.cuda.Event()
@@ -176,9 +195,6 @@ class InferWorker(QObject):
                         done = torch.cuda.Event()
                         done.record(side)
                     pending.append((frame, host, done))
-                except RuntimeError:   # zero mask instead of a crash, like inference() (infer.py:354-356)
-                    self.text_output.emit('RuntimeError during inference (maybe not enough ram/vram?)')
-                    pending.append((frame, None, None))
                 while len(pending) > 2:          # two frames in flight
                     finish(pending.pop(0))
             while pending:

@@ -112,6 +112,7 @@ class RcclDataParallel(nn.Module):
         self.module = module
         self.group = group
         self._synced_init = False
+        self._buffers_diverged = False   # a training forward has updated this replica's BatchNorm statistics
 
     def forward(self, *args, **kwargs):
         if world_size() > 1:
@@ -120,6 +121,13 @@ class RcclDataParallel(nn.Module):
                 self._synced_init = True                            # every step; replicas never diverge here)
             if self.module.training:
                 broadcast_buffers(self.module, 0, self.group)
+                self._buffers_diverged = True
+            elif self._buffers_diverged:
+                # first eval forward after a training phase: every replica has since updated its running statistics from
+                # its OWN last batch.  nn.DataParallel evaluates all replicas with device 0's buffers, and the state dict
+                # that gets saved is rank 0's — validate exactly that model on every rank.
+                broadcast_buffers(self.module, 0, self.group)
+                self._buffers_diverged = False
             self.module._grad_sync_factory = self._make_bucketer
         else:
             self.module._grad_sync_factory = None

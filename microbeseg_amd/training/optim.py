@@ -1,0 +1,117 @@
+"""Adam (amsgrad) of the training hot path as ONE HIP launch per step.
+
+The reference trains with ``torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-08, weight_decay=0,
+amsgrad=True)`` (src/training/train.py:380-385).  On PyTorch-ROCm that is ~8 multi-tensor launches per step plus, in
+this build, one weight repack per convolution operand (74 small launches).  ``FusedAdam`` keeps the same semantics and
+the ``torch.optim.Optimizer`` interface (``param_groups[...]['lr']`` is what ``ReduceLROnPlateau`` drives,
+``state_dict()`` holds ``step / exp_avg / exp_avg_sq / max_exp_avg_sq`` per parameter like the stock optimizer) but lays
+the network out for the update:
+
+* parameters, gradients and the three moment tensors are views of five flat fp32 arenas (the parameters are re-pointed
+  once, at construction), so the update of all 46 M parameters of the default DU-Net is ``mseg_adam_amsgrad_step`` on one
+  range: 36 B per parameter at HBM speed;
+* the explicit backward of ``engine.py`` writes each gradient straight into its arena view (``p.grad`` is allocated
+  once and never freed: ``zero_grad`` only marks it as consumed), so no gradient is copied or accumulated by autograd;
+* right after the update all packed GEMM operands of the convolutions are refreshed in one launch
+  (``engine.repack_all``), the next forward / backward finds them current.
+"""
+import torch
+from torch.optim.optimizer import Optimizer
+
+from .. import _lib
+
+
+class FusedAdam(Optimizer):
+    """``torch.optim.Adam(..., amsgrad=True, weight_decay=0)`` for fp32 CUDA (ROCm) parameters of one device."""
+
+    def __init__(self, params, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True):
+        if not lr > 0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not eps >= 0:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError(f"Invalid betas: {betas}")
+        if weight_decay != 0 or not amsgrad:
+            raise ValueError("FusedAdam implements the reference's configuration only: amsgrad=True, weight_decay=0")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        self._groups = []       # per param group: (params, flat p, g, m, v, vmax)
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                continue
+            dev = ps[0].device
+            for p in ps:
+                if not p.is_cuda or p.dtype != torch.float32 or p.device != dev:
+                    raise RuntimeError("FusedAdam: fp32 parameters on one CUDA (ROCm) device expected — the HIP path "
+                                       "has no CPU fallback")
+            offs, n = [], 0
+            for p in ps:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4          # every view 16-byte aligned
+            flat = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(5)]
+            fp, fg, fm, fv, fx = flat
+            with torch.no_grad():
+                for p, o in zip(ps, offs):
+                    k = p.numel()
+                    fp[o:o + k].copy_(p.detach().reshape(-1))
+                    p.data = fp[o:o + k].view_as(p)
+                    p.grad = fg[o:o + k].view_as(p)
+                    p.__dict__["_mseg_grad_direct"] = True     # engine.backward writes the gradient in place
+                    p.__dict__["_mseg_grad_fresh"] = True      # ... once per zero_grad()
+                    st = self.state[p]
+                    st["step"] = 0
+                    st["exp_avg"] = fm[o:o + k].view_as(p)
+                    st["exp_avg_sq"] = fv[o:o + k].view_as(p)
+                    st["max_exp_avg_sq"] = fx[o:o + k].view_as(p)
+            self._groups.append((group, ps, flat, n))
+
+    def zero_grad(self, set_to_none=True):
+        """The gradient arena is persistent: the next backward overwrites it (set_to_none semantics without the frees)."""
+        for _, ps, flat, _ in self._groups:
+            for p in ps:
+                p.__dict__["_mseg_grad_fresh"] = True
+                if p.grad is None:                 # somebody dropped the view: restore it
+                    raise RuntimeError("FusedAdam: p.grad was replaced; gradients must stay views of the arena")
+
+    def load_state_dict(self, state_dict):
+        """values are copied INTO the arenas (the state tensors must stay views of them)"""
+        views = {id(p): dict(self.state[p]) for _, ps, _, _ in self._groups for p in ps}
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for _, ps, _, _ in self._groups:
+                for p in ps:
+                    new, old = self.state[p], views[id(p)]
+                    for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                        old[key].copy_(new[key])
+                        new[key] = old[key]
+                    new["step"] = int(new["step"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        from .. import engine
+        for group, ps, (fp, fg, fm, fv, fx), n in self._groups:
+            step = self.state[ps[0]]["step"] + 1
+            b1, b2 = group["betas"]
+            _lib.check(lib.mseg_adam_amsgrad_step(fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr(),
+                                                  fx.data_ptr(), n, float(group["lr"]), b1, b2, group["eps"], step,
+                                                  stream), "adam_amsgrad_step")
+            for p in ps:
+                self.state[p]["step"] = step
+            torch.autograd.graph.increment_version(ps)   # the kernel wrote through raw pointers
+            engine.repack_all(ps)
+        return loss
+
+
+def make_adam(params, lr=8e-4, capturable=False):
+    """The reference's Adam configuration (train.py:380-385).  FusedAdam, or — for hipGraph capture, which needs the
+    step counters on the device — torch's capturable implementation with the same hyper-parameters."""
+    if capturable:
+        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True,
+                                capturable=True)
+    return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)

@@ -89,6 +89,7 @@ class Ranger(Optimizer):
                                         rows, beta1, beta2, group['eps'], step_size * group['lr'],
                                         int(n_sma > self.N_sma_threshhold), do_gc, lookahead, self.alpha,
                                         torch.cuda.current_stream().cuda_stream), "ranger_step")
+        torch.autograd.graph.increment_version(p)    # written through a raw pointer: packed operands are now stale
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -46,3 +46,57 @@ def rel_err(a, b, floor=0.0):
 def grad_floor(fx, prefix="g/"):
     """1e-3 x the largest gradient magnitude of the fixture: the scale below which a gradient counts as zero."""
     return 1e-3 * max(float(np.abs(v).max()) for k, v in fx.items() if k.startswith(prefix))
+
+
+def bf16_rule(kind, xs, ws):
+    """which of (forward, data gradient, weight gradient) of a layer the engine runs with bf16 operands: mirror of
+    engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32)"""
+    N, cin, H, W = xs
+
+    def rows_ok(h, w, pix):                               # pixel blocks of the bf16 weight-gradient kernel
+        th = pix // (8 if w % 8 == 0 else 4)
+        return w % 4 == 0 and h * 2 >= ((h + th - 1) // th) * th
+    if kind == "up":                                      # P = the layer's input (H x W)
+        return (True, True, rows_ok(H, W, 32))
+    if kind == "pool":                                    # P = dz (H/2 x W/2); data gradient: whole 128-row parity tiles
+        return (True, (N * H * W) % 512 == 0, H % 2 == 0 and W % 2 == 0 and rows_ok(H // 2, W // 2, 32))
+    if cin <= 4:
+        return (False, False, False)
+    return (True, True, rows_ok(H, W, 64))   # forward / data gradient: halo kernel, or the gather kernel where it does not tile
+
+
+class NodeTrace:
+    """records every engine Node of a forward pass (execution order) by wrapping engine.norm_stats"""
+
+    def __enter__(self):
+        from microbeseg_amd import engine
+        self.engine, self.nodes, self.orig = engine, [], engine.norm_stats
+
+        def wrapped(node, *a, **k):
+            self.nodes.append(node)
+            return self.orig(node, *a, **k)
+        engine.norm_stats = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.engine.norm_stats = self.orig
+        return False
+
+    def relu_masks(self):
+        """the HIP path's ReLU decisions, NCHW bool on the CPU, one per activated layer in execution order"""
+        return [(n.z > 0).permute(0, 3, 1, 2).contiguous().cpu() for n in self.nodes if n.act == 1]   # _lib.ACT["relu"]
+
+
+def check_relu_flips(masks, trace, max_frac=1e-4, tol=1e-4):
+    """ReLU decisions that differ between the HIP path and the fp32 oracle: each must sit at a pre-activation within
+    the forward tolerance of 0 (|z_ref| <= tol * max|z| of its layer), and there must be few of them."""
+    total = flips = 0
+    for m, z in zip(masks, trace):
+        d = m != (z > 0)
+        n = int(d.sum())
+        total += d.numel()
+        flips += n
+        if n:
+            assert z[d].abs().max().item() <= tol * z.abs().max().item(), "a ReLU decision flipped away from z = 0"
+            assert n <= max(4, max_frac * d.numel()), f"{n} flipped ReLU decisions in a layer of {d.numel()}"
+    return flips, total

@@ -1,0 +1,254 @@
+"""GPU (MI355X): parity at the FULL sizes BASELINE.json names — one test per config.
+
+  configs[1]  DU-Net [64,1024], 256x256, fp32: batch 2 forward + every parameter gradient against the CPU oracle
+              (fp32 = the reference arithmetic, fp64 = ground truth), ReLU/BatchNorm (the bench headline) and
+              ReLU/GroupNorm; batch 32 through size-independent properties.
+  configs[2]  the same network at 320x320 in bf16 mode against the oracle with the same rounding points.
+  configs[4]  2048x2048 frames: InferWorker.infer_stack on a [T=2] stack, labels bit-exact against the C oracle of the
+              post-processing fed the network's own prediction maps; synthetic ~2500-cell maps bit-exact as well.
+  large frame 3200x3200 (level-0 tensor > 2 GiB): whole-frame forward == the same network on two overlapping halves.
+
+The deep levels (512 / 1024 channels on 16x16 maps, split-K launches, the narrow-row weight-gradient kernels) are
+reached only at these sizes.  CPU oracle cost: ~5 s (fp32) + ~15 s (fp64) per full-size network step.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import NodeTrace as _NodeTrace, bf16_rule, check_relu_flips as _check_flips, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4                 # BASELINE.json north_star: distance maps within 1e-4 relative fp32
+FILTERS = (64, 1024)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _hip_step(net, x, gos, dev, precision="fp32"):
+    from microbeseg_amd import engine
+    net.train()
+    with _NodeTrace() as tr, engine.precision_scope(precision):
+        outs = net(x.to(dev))
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        torch.autograd.backward(outs, [g.to(dev) for g in gos])
+        masks = tr.relu_masks()
+    return [o.detach().cpu() for o in outs], masks
+
+
+def _oracle_step(sd, x, gos, ut, act, norm, dtype, masks=None, trace=None, rule=None):
+    from oracle import unet_ref
+    params = {k: (v.clone().to(dtype).requires_grad_(True) if v.is_floating_point() and "running" not in k
+                  else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    unet_ref.RELU_MASKS = iter(masks) if masks is not None else None
+    unet_ref.RELU_TRACE = trace
+    unet_ref.BF16_RULE = rule
+    try:
+        ref = unet_ref.unet_forward(params, x.to(dtype), ut, act, norm, FILTERS, training=True, update_running_stats=True)
+        ref = ref if isinstance(ref, tuple) else (ref,)
+        torch.autograd.backward(ref, [g.to(dtype) for g in gos])
+    finally:
+        unet_ref.RELU_MASKS = unet_ref.RELU_TRACE = unet_ref.BF16_RULE = None
+    return params, [r.detach() for r in ref]
+
+
+@pytest.mark.parametrize("norm", ["bn", "gn"])
+def test_config1_full_network_batch2_vs_oracle(norm, dev):
+    """configs[1] network and crop size; forward 1e-4, parameter gradients as accurate as the reference arithmetic.
+
+    ReLU: the gradient comparison replays the oracle's backward with the HIP path's ReLU masks (oracle/unet_ref.py
+    RELU_MASKS), which removes exactly the contribution of the few pre-activations whose sign the two summation orders
+    disagree on; those are counted and bounded (_check_flips).  Everything else is held to the same rule as the smooth
+    activations: error vs fp64 below max(5e-4, 4 x the fp32 oracle's own error vs fp64)."""
+    from microbeseg_amd.utils.unets import build_unet
+    torch.manual_seed(77)
+    net = build_unet("DU", "relu", "conv", norm, dev, 1, ch_out=1, filters=FILTERS)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(2, 1, 256, 256) * 2 - 1
+    gos = [torch.randn(2, 1, 256, 256) for _ in range(2)]
+    outs, masks = _hip_step(net, x, gos, dev)
+    trace = []
+    p32, r32 = _oracle_step(sd, x, gos, "DU", "relu", norm, torch.float32, masks=masks, trace=trace)
+    for o, r in zip(outs, r32):
+        assert rel_err(o, r) < TOL
+    flips, total = _check_flips(masks, trace)
+    p64, _ = _oracle_step(sd, x, gos, "DU", "relu", norm, torch.float64, masks=masks)
+    floor = 1e-3 * max(p.grad.abs().max().item() for p in p64.values() if getattr(p, "grad", None) is not None)
+    worst = (0.0, None)
+    for k, p in net.named_parameters():
+        e_ref = rel_err(p32[k].grad, p64[k].grad, floor)
+        e_hip = rel_err(p.grad.cpu(), p64[k].grad, floor)
+        worst = max(worst, (e_hip / max(5e-4, 4 * e_ref), k))
+        assert e_hip < max(5e-4, 4 * e_ref), (k, e_hip, e_ref, f"{flips} flips / {total}")
+    if norm == "bn":
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                assert rel_err(v.cpu(), p32[k]) < TOL, k
+    print(f"[{norm}] ReLU flips {flips}/{total}; worst gradient error ratio {worst[0]:.2f} ({worst[1]})")
+
+
+def test_config1_batch32_properties(dev):
+    """configs[1] at its full batch (32 x 256x256): finite, bit-reproducible training step, and — in eval mode, where
+    BatchNorm uses running statistics and samples are independent — equal to two batch-16 halves."""
+    from microbeseg_amd.training.losses import get_loss
+    from microbeseg_amd.utils.unets import build_unet
+    torch.manual_seed(5)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(32, 1, 256, 256, generator=g) * 2 - 1).to(dev)
+    lb, lc = torch.rand(32, 1, 256, 256, generator=g).to(dev), torch.rand(32, 1, 256, 256, generator=g).to(dev)
+    crit = get_loss("smooth_l1", "distance")
+
+    def step():
+        net.load_state_dict(sd0)
+        net.train()
+        for p in net.parameters():
+            p.grad = None
+        border, cell = net(x)
+        loss = crit["border"](border, lb) + crit["cell"](cell, lc)
+        loss.backward()
+        return loss.item(), border.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+
+    l1, b1, g1 = step()
+    l2, b2, g2 = step()
+    assert np.isfinite(l1) and torch.isfinite(b1).all() and all(torch.isfinite(t).all() for t in g1)
+    assert l1 == l2 and torch.equal(b1, b2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)                      # fixed-order reductions, no atomics: bit-reproducible
+    net.load_state_dict(sd0)
+    net.eval()
+    with torch.no_grad():
+        full = net(x)
+        lo, hi = net(x[:16].contiguous()), net(x[16:].contiguous())
+    for f, a, b in zip(full, lo, hi):
+        assert rel_err(torch.cat([a, b]).cpu(), f.cpu()) < 1e-5
+
+
+def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
+    """configs[2]: [64,1024] DU-Net, 320x320 crops, bf16 mode, against oracle/unet_ref.py BF16_RULE (the reference
+    arithmetic with the build's rounding points).  bf16 tolerance (see test_bf16_mode_matches_bf16_oracle): outputs
+    within 5e-3 of the bf16 oracle and within 3e-2 of fp32; parameter gradients in relative L2 within max(2e-2, what bf16
+    rounding itself does to that gradient).  ReLU decisions are replayed from the HIP path as in the fp32 test."""
+    from microbeseg_amd.utils.unets import build_unet
+    torch.manual_seed(78)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(2, 1, 320, 320) * 2 - 1
+    gos = [torch.randn(2, 1, 320, 320) for _ in range(2)]
+    outs, masks = _hip_step(net, x, gos, dev, precision="bf16")
+    trace = []
+    p16, r16 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks, trace=trace, rule=bf16_rule)
+    p32, r32 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks)
+    for o, a, b in zip(outs, r16, r32):
+        assert rel_err(o, a) < 5e-3
+        assert 1e-4 < rel_err(o, b) < 3e-2
+    # a bf16 ReLU decision flips wherever |z| is within bf16 rounding noise of 0: bounded at 1e-2 of the elements
+    for m, z in zip(masks, trace):
+        d = m != (z > 0)
+        if d.any():
+            assert z[d].abs().max().item() <= 2e-2 * z.abs().max().item()
+            assert int(d.sum()) <= 1e-2 * d.numel()
+    floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
+
+    def l2(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    for k, p in net.named_parameters():
+        if p32[k].grad.abs().max().item() <= floor:
+            continue
+        noise = l2(p16[k].grad, p32[k].grad)
+        assert l2(p.grad.cpu(), p16[k].grad) < max(2e-2, noise), k
+        assert l2(p.grad.cpu(), p32[k].grad) < max(4e-2, 2 * noise), k
+
+
+def _write_checkpoint(tmp_path, net, norm="bn"):
+    torch.save(net.state_dict(), str(tmp_path / "distance_model_00.pth"))
+    with open(tmp_path / "distance_model_00.json", "w") as f:
+        json.dump({"architecture": ["DU", "conv", "relu", norm, list(FILTERS)], "label_type": "distance"}, f)
+    return tmp_path / "distance_model_00"
+
+
+def test_config4_stack_2048_through_infer_worker(tmp_path, dev):
+    """configs[4]: a [T=2, 2048, 2048] uint16 stack through InferWorker.infer_stack (pipelined network + watershed).
+    The masks must equal, bit for bit, the C oracle of the post-processing applied to the network's own prediction
+    maps (downloaded from the HIP forward), and the frame-by-frame inference() path."""
+    from microbeseg_amd.inference.infer import InferWorker
+    from microbeseg_amd.utils import synth
+    from microbeseg_amd.utils.unets import build_unet
+    from oracle import postproc_ref
+    torch.manual_seed(3)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
+    with torch.no_grad():      # random BN statistics would be all (0, 1): give the heads a usable output range
+        for d in (net.decoder1Conv[-1], net.decoder2Conv[-1]):
+            d.weight.mul_(4.0)
+            d.bias.fill_(0.3)
+    worker = InferWorker(model=str(_write_checkpoint(tmp_path, net)), device="cuda:0", ths=(0.10, 0.45))
+    rng = np.random.Generator(np.random.PCG64(2024))
+    S = 2048
+    frames = []
+    for _ in range(2):
+        cell, _ = synth.synth_prediction_maps(rng, S, S, 2500, rmin=5.0, rmax=13.0)
+        frames.append(np.clip(cell * 50000 + rng.normal(0, 800, cell.shape), 0, 65535).astype(np.uint16))
+    stack = np.stack(frames)
+    got = worker.infer_stack(stack)
+    assert got.shape == stack.shape and got.dtype == np.uint16
+    n_inst = []
+    for t in range(2):
+        f = stack[t]
+        x = 2 * (f.astype(np.float32) - f.min()) / (f.max() - f.min()) - 1
+        with torch.no_grad():
+            border, cell = worker.net(torch.from_numpy(x[None, None]).to(dev))
+        want = postproc_ref.distance_postprocessing(border[0, 0].cpu().numpy()[..., None],
+                                                    cell[0, 0].cpu().numpy()[..., None], 0.45, 0.10)
+        assert np.array_equal(got[t], want), f"frame {t}: {int((got[t] != want).sum())} pixels differ"
+        one = worker.inference(f, f.min(), f.max(), [0, 0])
+        assert np.array_equal(one, want)
+        n_inst.append(int(want.max()))
+    print("instances per frame:", n_inst)
+
+
+def test_config4_postprocessing_2048_synthetic_maps(dev):
+    """2048x2048 prediction maps with ~2500 cells (the bench's inference workload): labels bit-exact vs the C oracle."""
+    from microbeseg_amd.inference import postprocessing as pp
+    from microbeseg_amd.utils import synth
+    from oracle import postproc_ref
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cell, border = synth.synth_prediction_maps(rng, 2048, 2048, 2500, rmin=5.0, rmax=13.0)
+    labels, n, status = pp.distance_postprocessing_device(torch.from_numpy(border).to(dev),
+                                                          torch.from_numpy(cell).to(dev), 0.45, 0.10)
+    want = postproc_ref.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
+    assert np.array_equal(labels.cpu().numpy().view(np.uint16), want)
+    assert int(n) == int(want.max()) and int(n) > 1500
+
+
+def test_frame_3200_equals_overlapping_halves(dev):
+    """A 3200x3200 frame (one of the reference's tested shapes, utils.py:137-138): its level-0 tensor is 2.6 GB, beyond
+    32-bit buffer offsets.  In eval mode (BatchNorm = per-channel affine, no global statistics) the whole-frame output
+    must equal the output of the same network on two halves cut with a halo wider than the receptive field
+    (107 px for 5 levels; 128 keeps the 16-px level alignment): top rows [0, 1728) and bottom rows [1472, 3200)."""
+    from microbeseg_amd.utils.unets import build_unet
+    torch.manual_seed(4)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(1, 1, 3200, 3200, generator=g) * 2 - 1).to(dev)
+    with torch.no_grad():
+        full = [o.cpu() for o in net(x)]
+        top = [o.cpu() for o in net(x[:, :, :1728].contiguous())]
+        bot = [o.cpu() for o in net(x[:, :, 1472:].contiguous())]
+    for f, a, b in zip(full, top, bot):
+        assert torch.isfinite(f).all()
+        assert rel_err(a[:, :, :1600], f[:, :, :1600]) < 1e-5
+        assert rel_err(b[:, :, 128:], f[:, :, 1600:]) < 1e-5

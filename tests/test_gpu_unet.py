@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import VARIANTS, grad_floor, load_npz, rel_err, state_from, variant
+from helpers import VARIANTS, bf16_rule as _bf16_rule, grad_floor, load_npz, rel_err, state_from, variant
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -72,7 +72,43 @@ def test_net_matches_reference_fixture(name, dev):
             assert np.allclose(sd[k[6:]].cpu().numpy(), v, rtol=1e-4, atol=1e-6), k
 
 
-def _traj(fxname, name, make_opt, steps, dev, tol_w):
+def _oracle_traj(fx, name, make_ref_opt, steps, dtype):
+    """the same trajectory through oracle/unet_ref.py on the CPU in `dtype` (fp32 = the reference arithmetic,
+    fp64 = ground truth): per-step losses and the final state"""
+    from oracle import unet_ref
+    ut, act, norm, filters, ch_out, label_type, pool = variant(name)
+    params = {k: ((v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in state_from(fx).items()}
+    for k, v in params.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    opt = make_ref_opt([v for v in params.values() if v.requires_grad])
+    losses = []
+    for s in range(steps):
+        opt.zero_grad()
+        b = s % 2
+        outs = unet_ref.unet_forward(params, torch.from_numpy(fx[f"x{b}"]).to(dtype), ut, act, norm, filters,
+                                     training=True, update_running_stats=True)
+        l1 = torch.from_numpy(fx[f"label1_{b}"])
+        if label_type == "distance":
+            l2 = torch.from_numpy(fx[f"label2_{b}"])
+            loss = unet_ref.regression_loss(outs[0], l1.to(dtype)) + unet_ref.regression_loss(outs[1], l2.to(dtype))
+        else:
+            loss = unet_ref.ce_dice(outs, l1)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    return np.array(losses), {k: v.detach() for k, v in params.items()}
+
+
+def _traj(fxname, name, make_opt, make_ref_opt, steps, dev):
+    """N optimisation steps on the HIP path from the fixture's initial weights and batches.
+
+    Two yardsticks.  (1) The reference's own trajectory (fixture, torch CPU fp32): losses within 1e-3.  (2) Tight, per
+    tensor: Adam / RAdam updates are sign-like (m / sqrt(v)), so a parameter whose gradient is rounding noise (e.g. a conv
+    bias in front of BatchNorm: analytically zero) moves by +-lr per step in an arbitrary direction in ANY fp32
+    implementation, while well-conditioned parameters follow the exact trajectory closely.  The fp64 oracle trajectory
+    is the ground truth and the fp32 oracle's distance from it (e_ref, per tensor) is what fp32 arithmetic can achieve:
+    the HIP path must stay within max(2e-4, 4 e_ref) of the fp64 trajectory, for every tensor and for the losses."""
     label_type = variant(name)[5]
     fx = load_npz(fxname)
     net = _build(name, dev, state_from(fx))
@@ -85,32 +121,87 @@ def _traj(fxname, name, make_opt, steps, dev, tol_w):
         loss.backward()
         opt.step()
         losses.append(loss.item())
+    losses = np.array(losses)
     assert np.allclose(losses, fx["losses"], rtol=1e-3, atol=1e-5), (losses, fx["losses"])
+    l32, sd32 = _oracle_traj(fx, name, make_ref_opt, steps, torch.float32)
+    l64, sd64 = _oracle_traj(fx, name, make_ref_opt, steps, torch.float64)
+    e_l = np.abs(l32 - l64) / np.abs(l64)
+    assert (np.abs(losses - l64) / np.abs(l64) <= np.maximum(2e-5, 4 * e_l.max())).all(), (losses, l64, e_l)
     sd = net.state_dict()
-    for k, v in fx.items():
-        if k.startswith("final/") and not k.endswith("num_batches_tracked"):
-            assert rel_err(sd[k[6:]].cpu(), v) < tol_w, k
+    report = []
+    for k, v64 in sd64.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        e_ref = rel_err(sd32[k], v64)
+        e_hip = rel_err(sd[k].cpu(), v64)
+        report.append((e_hip / max(2e-4, 4 * e_ref), k, e_hip, e_ref))
+        assert e_hip <= max(2e-4, 4 * e_ref), (k, e_hip, e_ref)
+        assert rel_err(sd[k].cpu(), fx["final/" + k]) < 2e-2, k      # and never far from the reference's own end point
+    print("worst tensors (ratio, name, e_hip, e_ref):", sorted(report, reverse=True)[:3])
 
 
-def test_adam_trajectory(dev):
-    _traj("traj_adam_DU_bn_relu.npz", "DU_bn_relu_8_16",
-          lambda ps: torch.optim.Adam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True), 8, dev,
-          5e-3)
+def _adam(ps):
+    return torch.optim.Adam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+
+
+def _fused_adam(ps):
+    from microbeseg_amd.training.optim import FusedAdam
+    return FusedAdam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+
+
+@pytest.mark.parametrize("mk", [_adam, _fused_adam], ids=["torch_adam", "fused_adam"])
+def test_adam_trajectory(mk, dev):
+    _traj("traj_adam_DU_bn_relu.npz", "DU_bn_relu_8_16", mk, _adam, 8, dev)
 
 
 def test_ranger_trajectory(dev):
     from microbeseg_amd.training.ranger2020 import Ranger
+    from oracle import unet_ref
+
     def mk(ps):
         with contextlib.redirect_stdout(io.StringIO()):
             return Ranger(ps, lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6,
                           weight_decay=0, use_gc=True, gc_conv_only=False, gc_loc=True)
-    _traj("traj_ranger_DU_bn_mish.npz", "DU_bn_mish_8_16", mk, 14, dev, 2e-2)
+    _traj("traj_ranger_DU_bn_mish.npz", "DU_bn_mish_8_16", mk,
+          lambda ps: unet_ref.RangerRef(ps, lr=6e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-6),
+          14, dev)
 
 
-def test_adam_ce_dice_trajectory(dev):
-    _traj("traj_adam_U_gn_relu.npz", "U_gn_relu_8_16",
-          lambda ps: torch.optim.Adam(ps, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True), 6, dev,
-          5e-3)
+@pytest.mark.parametrize("mk", [_adam, _fused_adam], ids=["torch_adam", "fused_adam"])
+def test_adam_ce_dice_trajectory(mk, dev):
+    _traj("traj_adam_U_gn_relu.npz", "U_gn_relu_8_16", mk, _adam, 6, dev)
+
+
+def test_fused_adam_equals_torch_adam(dev):
+    """training/optim.FusedAdam (one launch over the flat arenas) against torch.optim.Adam(amsgrad=True) on the same
+    parameters and gradients, 12 steps with a learning-rate change in between: same update to fp32 rounding (the kernel
+    contracts multiply-adds), identical step counters and state layout."""
+    from microbeseg_amd.training.optim import FusedAdam
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 32, 3, 3), (64,), (7,), (33, 5, 2, 2), (1, 64, 1, 1), (1,)]
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    oa = torch.optim.Adam(pa, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+    ob = FusedAdam(pb, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+    for step in range(12):
+        if step == 6:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 2e-4            # what ReduceLROnPlateau does
+        grads = [torch.randn(s, generator=g) * (10.0 ** (step % 3 - 2)) for s in shapes]
+        ob.zero_grad()
+        for a, b, gr in zip(pa, pb, grads):
+            a.grad = gr.clone().to(dev)
+            b.grad.copy_(gr.to(dev))
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6
+    for a, b in zip(pa, pb):
+        sa, sb = oa.state[a], ob.state[b]
+        assert int(sa["step"]) == sb["step"] == 12
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert rel_err(sb[key].cpu(), sa[key].cpu()) < 2e-6, key
 
 
 def _l2_rel(a, b):
@@ -123,15 +214,19 @@ def _l2_rel(a, b):
     ("U", "mish", "gn", (32, 64), 96, 2),
     ("DU", "elu", "bn", (64, 128), 48, 2),       # 64-channel level 0 like the default net
     ("DU", "relu", "bn", (64, 128), 48, 2),      # ReLU: see the note on mask flips below
+    ("U", "relu", "gn", (32, 128), 64, 2),
 ])
 def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch, dev):
     """Same seeded weights / inputs through the HIP net and the CPU oracle, forward + parameter gradients.
 
     ReLU note: with ~3e5 activations per layer a few pre-activations land within fp32 rounding of 0, where the HIP
     and CPU summation orders disagree on the sign; each such flip switches one element of dz on/off (verified with
-    tools/diag_dz.py: gy and z agree to 1e-6, dz differs only at those elements).  With N(0,1) upstream gradients a
-    single flip moves max|dW| by ~1e-2, so the ReLU variant is checked in relative L2 norm; the smooth activations
-    (and the small ReLU fixtures above) are checked element-wise."""
+    tools/diag_dz.py: gy and z agree to 1e-6, dz differs only at those elements), and with N(0,1) upstream gradients a
+    single flip moves max|dW| by ~1e-2.  The flipped elements are identified (HIP mask != oracle mask), required to
+    sit at |z| <= 1e-4 max|z| and to be few (helpers.check_relu_flips), and exactly their contribution is removed by
+    replaying the oracle's backward with the HIP path's masks (oracle/unet_ref.py RELU_MASKS); everything else is held
+    to the same element-wise rule as the smooth activations."""
+    from helpers import NodeTrace, check_relu_flips
     from microbeseg_amd.utils.unets import build_unet
     from oracle import unet_ref
     torch.manual_seed(1234)
@@ -140,33 +235,39 @@ def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     x = torch.rand(batch, 1, size, size) * 2 - 1
     net.train()
-    outs = net(x.to(dev))
-    outs = outs if isinstance(outs, tuple) else (outs,)
-    gos = [torch.randn(o.shape) for o in outs]
-    torch.autograd.backward(outs, [g.to(dev) for g in gos])
+    with NodeTrace() as tr:
+        outs = net(x.to(dev))
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        gos = [torch.randn(o.shape) for o in outs]
+        torch.autograd.backward(outs, [g.to(dev) for g in gos])
+        masks = tr.relu_masks() if act == "relu" else None
 
-    def oracle(dtype):
+    def oracle(dtype, trace=None):
         params = {k: (v.clone().to(dtype).requires_grad_(True) if v.is_floating_point() and "running" not in k
                       else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
-        ref = unet_ref.unet_forward(params, x.to(dtype), ut, act, norm, filters, training=True,
-                                    update_running_stats=True)
-        ref = ref if isinstance(ref, tuple) else (ref,)
-        torch.autograd.backward(ref, [g.to(dtype) for g in gos])
+        unet_ref.RELU_MASKS = iter(masks) if masks is not None else None
+        unet_ref.RELU_TRACE = trace
+        try:
+            ref = unet_ref.unet_forward(params, x.to(dtype), ut, act, norm, filters, training=True,
+                                        update_running_stats=True)
+            ref = ref if isinstance(ref, tuple) else (ref,)
+            torch.autograd.backward(ref, [g.to(dtype) for g in gos])
+        finally:
+            unet_ref.RELU_MASKS = unet_ref.RELU_TRACE = None
         return params, ref
 
-    p32, r32 = oracle(torch.float32)     # the reference arithmetic (torch CPU fp32)
-    p64, r64 = oracle(torch.float64)     # ground truth
+    trace = [] if act == "relu" else None
+    p32, r32 = oracle(torch.float32, trace)     # the reference arithmetic (torch CPU fp32)
+    p64, r64 = oracle(torch.float64)            # ground truth
     for o, r in zip(outs, r32):
         assert rel_err(o.detach().cpu(), r.detach()) < TOL
+    if act == "relu":
+        flips, total = check_relu_flips(masks, trace)
+        print(f"ReLU decisions flipped: {flips} of {total}")
     # Parameter gradients of a deep BatchNorm net are ill-conditioned: torch-CPU fp32 itself is ~1e-3 away from the
     # fp64 truth.  The HIP path must be as accurate as the reference arithmetic: per parameter within 4x of the
     # fp32 oracle's own error, or no worse than the fp32 oracle's worst parameter, or within 5*TOL.
     floor = 1e-3 * max(p.grad.abs().max().item() for p in p64.values() if getattr(p, "grad", None) is not None)
-    if act == "relu":
-        for k, p in net.named_parameters():
-            if p64[k].grad.abs().max().item() > floor:
-                assert _l2_rel(p.grad.cpu(), p64[k].grad) < 2e-2, k
-        return
     e_ref_all = {k: rel_err(p32[k].grad, p64[k].grad, floor) for k, _ in net.named_parameters()}
     worst_ref = max(e_ref_all.values())
     for k, p in net.named_parameters():
@@ -175,23 +276,6 @@ def test_net_matches_oracle_on_larger_inputs(ut, act, norm, filters, size, batch
     for k, v in net.state_dict().items():
         if "running" in k:
             assert rel_err(v.cpu(), p32[k]) < 1e-4, k
-
-
-def _bf16_rule(kind, xs, ws):
-    """which of (forward, data gradient, weight gradient) of a layer the engine runs with bf16 operands: mirror of
-    engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32)"""
-    N, cin, H, W = xs
-
-    def rows_ok(h, w, pix):                               # pixel blocks of the bf16 weight-gradient kernel
-        th = pix // (8 if w % 8 == 0 else 4)
-        return w % 4 == 0 and h * 2 >= ((h + th - 1) // th) * th
-    if kind == "up":                                      # P = the layer's input (H x W)
-        return (True, True, rows_ok(H, W, 32))
-    if kind == "pool":                                    # P = dz (H/2 x W/2); data gradient: whole 128-row parity tiles
-        return (True, (N * H * W) % 512 == 0, H % 2 == 0 and W % 2 == 0 and rows_ok(H // 2, W // 2, 32))
-    if cin <= 4:
-        return (False, False, False)
-    return (True, True, rows_ok(H, W, 64))   # forward / data gradient: halo kernel, or the gather kernel where it does not tile
 
 
 @pytest.mark.parametrize("ut,act,norm,filters,size,batch", [("DU", "elu", "bn", (64, 128), 64, 2),

@@ -88,3 +88,26 @@ def _wrapper_job(rank, world):
 def test_wrapper_broadcasts_parameters_from_rank0():
     out = _run(_wrapper_job)
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][2]
+
+
+def _eval_switch_job(rank, world):
+    """training forwards let each replica's BatchNorm statistics drift (per-replica batches); the first eval forward after
+    them must run on rank 0's buffers — the ones the checkpoint holds (parallel.py)."""
+    from microbeseg_amd.parallel import RcclDataParallel
+    torch.manual_seed(0)
+    m = RcclDataParallel(torch.nn.Sequential(torch.nn.Conv2d(1, 4, 1), torch.nn.BatchNorm2d(4)))
+    g = torch.Generator().manual_seed(50 + rank)
+    m.train()
+    for _ in range(3):
+        m(torch.randn(8, 1, 5, 5, generator=g) * (1 + 3 * rank))      # rank 1 sees much larger inputs
+    drift = m.module[1].running_var.clone()
+    m.eval()
+    y = m(torch.ones(2, 1, 5, 5))
+    return drift.tolist(), m.module[1].running_var.tolist(), y.detach().flatten().tolist()
+
+
+def test_eval_after_training_uses_rank0_buffers():
+    out = _run(_eval_switch_job)
+    assert out[0][0] != out[1][0]                       # the replicas did drift apart while training
+    assert out[0][1] == out[1][1] == out[0][0]          # ... and validate on rank 0's statistics
+    assert out[0][2] == out[1][2]
