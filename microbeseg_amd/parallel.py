@@ -137,6 +137,14 @@ class RcclDataParallel(nn.Module):
         return GradBucketer(group=self.group)
 
 
+def sync_eval_buffers(net):
+    """Called by EVERY rank at the start of a validation phase (also by ranks that will not run a single validation
+    batch): replicas whose BatchNorm statistics have drifted during the training phase take rank 0's."""
+    if isinstance(net, RcclDataParallel) and world_size() > 1 and net._buffers_diverged:
+        broadcast_buffers(net.module, 0, net.group)
+        net._buffers_diverged = False
+
+
 def allreduce_dice_sums(sums, total):
     """ce_dice: Dice numerators/denominators over the global batch (C3).  Returns (sums, dice_weight)."""
     w = world_size()

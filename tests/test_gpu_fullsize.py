@@ -133,9 +133,16 @@ def test_config1_batch32_properties(dev):
 
 def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
     """configs[2]: [64,1024] DU-Net, 320x320 crops, bf16 mode, against oracle/unet_ref.py BF16_RULE (the reference
-    arithmetic with the build's rounding points).  bf16 tolerance (see test_bf16_mode_matches_bf16_oracle): outputs
-    within 5e-3 of the bf16 oracle and within 3e-2 of fp32; parameter gradients in relative L2 within max(2e-2, what bf16
-    rounding itself does to that gradient).  ReLU decisions are replayed from the HIP path as in the fp32 test."""
+    arithmetic with the build's rounding points) and against the fp32 reference arithmetic.
+
+    Through the 23 convolutions of the 5-level network bf16 rounding compounds: an operand whose fp32 value differs in the
+    last bits between two implementations rounds to the other bf16 neighbour (2^-8 relative), so two bf16 implementations
+    with IDENTICAL rounding points end ~sqrt(2) x the bf16-vs-fp32 distance apart (independent rounding noise), not 1e-4.
+    The own tolerance of this mode is therefore stated relative to what bf16 rounding itself does, d_ref = distance of
+    the bf16 oracle from the fp32 oracle (relative L2): the HIP path must be as close to fp32 as the model of its rounding
+    points (<= 1.25 d_ref), not further from that model than independent noise (<= 1.6 d_ref), really bf16 (>= 0.5
+    d_ref), and d_ref itself must be sane (< 3e-2 on the outputs).  Same rule per parameter gradient, with a 2e-2 floor.
+    ReLU decisions are replayed from the HIP path as in the fp32 test; their flip rate is bounded at 1e-2."""
     from microbeseg_amd.utils.unets import build_unet
     torch.manual_seed(78)
     net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
@@ -146,26 +153,33 @@ def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
     trace = []
     p16, r16 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks, trace=trace, rule=bf16_rule)
     p32, r32 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks)
-    for o, a, b in zip(outs, r16, r32):
-        assert rel_err(o, a) < 5e-3
-        assert 1e-4 < rel_err(o, b) < 3e-2
-    # a bf16 ReLU decision flips wherever |z| is within bf16 rounding noise of 0: bounded at 1e-2 of the elements
-    for m, z in zip(masks, trace):
-        d = m != (z > 0)
-        if d.any():
-            assert z[d].abs().max().item() <= 2e-2 * z.abs().max().item()
-            assert int(d.sum()) <= 1e-2 * d.numel()
-    floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
 
     def l2(a, b):
         a, b = a.double().flatten(), b.double().flatten()
         return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    for o, a, b in zip(outs, r16, r32):
+        d_ref, d_model, d_fp32 = l2(a, b), l2(o, a), l2(o, b)
+        print(f"output: bf16 oracle vs fp32 {d_ref:.2e}; HIP vs bf16 oracle {d_model:.2e}; HIP vs fp32 {d_fp32:.2e}; "
+              f"max-norm HIP vs bf16 oracle {rel_err(o, a):.2e}")
+        assert 1e-4 < d_ref < 3e-2
+        assert 0.5 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 1.6 * d_ref
+    # a bf16 ReLU decision flips wherever |z| is within bf16 rounding noise of 0: bounded at 1e-2 of the elements
+    for m, z in zip(masks, trace):
+        d = m != (z > 0)
+        if d.any():
+            assert z[d].abs().max().item() <= 5e-2 * z.abs().max().item()
+            assert int(d.sum()) <= 1e-2 * d.numel()
+    floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
+    worst = []
     for k, p in net.named_parameters():
         if p32[k].grad.abs().max().item() <= floor:
             continue
-        noise = l2(p16[k].grad, p32[k].grad)
-        assert l2(p.grad.cpu(), p16[k].grad) < max(2e-2, noise), k
-        assert l2(p.grad.cpu(), p32[k].grad) < max(4e-2, 2 * noise), k
+        d_ref = l2(p16[k].grad, p32[k].grad)
+        d_model, d_fp32 = l2(p.grad.cpu(), p16[k].grad), l2(p.grad.cpu(), p32[k].grad)
+        worst.append((d_fp32 / max(2e-2, 1.25 * d_ref), k, d_ref, d_model, d_fp32))
+        assert d_fp32 < max(2e-2, 1.25 * d_ref), (k, d_ref, d_model, d_fp32)
+        assert d_model < max(2e-2, 1.6 * d_ref), (k, d_ref, d_model, d_fp32)
+    print("worst gradients (ratio, name, d_ref, d_model, d_fp32):", sorted(worst, reverse=True)[:3])
 
 
 def _write_checkpoint(tmp_path, net, norm="bn"):

@@ -71,6 +71,9 @@ def test_train_worker_host_logic_cpu(tmp_path, monkeypatch, label_type):
 
     monkeypatch.setattr(T, "build_unet", fake_build)
     monkeypatch.setattr(T, "get_loss", fake_loss)
+    # the product's Adam is the fused HIP optimizer (no CPU fallback); the host-logic test injects torch's
+    monkeypatch.setitem(T.OPTIMIZER_RECIPES["adam"], "make",
+                        lambda ps, lr: torch.optim.Adam(ps, lr=lr, betas=(0.9, 0.999), eps=1e-8, amsgrad=True))
     w = T.TrainWorker()
     w.augment = False      # the device augmentation needs the GPU; this test exercises the host logic only
     msgs, prog = [], []
