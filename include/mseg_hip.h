@@ -214,14 +214,15 @@ int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, 
 
 /* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
 /* torch.optim.Adam(amsgrad=True, weight_decay=0) on ONE flat range (train.py:380-385): p, g, exp_avg, exp_avg_sq,
- * max_exp_avg_sq of n elements; `step` = 1-based step count (bias corrections are evaluated on the host in fp64). */
-int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
-                           float beta1, float beta2, float eps, int step, void* stream);
+ * max_exp_avg_sq of n elements; `step` = 1-based step count.  Hyper-parameters are doubles (python floats): 1 - beta,
+ * the bias corrections and lr / bc1 are evaluated in fp64 and rounded to fp32 once, as torch does.                   */
+int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, double lr,
+                           double beta1, double beta2, double eps, int step, void* stream);
 /* One Ranger update of one parameter tensor (ranger2020.py:142-206): gradient centralisation over dims 1.. (do_gc, rows =
  * shape[0]), moments, rectified or plain-momentum update with step_lr = step_size * lr (host-side RAdam buffer,
  * ranger2020.py:160-176), and the lookahead blend every k-th step (lookahead = 1).                              */
-int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, int rows, float beta1,
-                     float beta2, float eps, float step_lr, int rectified, int do_gc, int lookahead, float alpha,
+int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, int rows, double beta1,
+                     double beta2, double eps, double step_lr, int rectified, int do_gc, int lookahead, double alpha,
                      void* stream);
 
 /* ---- inference post-processing (src/inference/postprocessing.py) --------------------------------------------

@@ -56,6 +56,7 @@ class MsegPackJob(C.Structure):
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
+_D = C.c_double
 _SZ = C.c_size_t
 
 # name -> (restype, argtypes); every symbol declared in include/mseg_hip.h
@@ -86,8 +87,8 @@ SIGNATURES = {
     "mseg_regression_loss_bwd": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),
     "mseg_ce_dice_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, C.c_double, _P, _P, _P]),
-    "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _P]),
-    "mseg_ranger_step": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _F, _F, _F, _F, _I, _I, _I, _F, _P]),
+    "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _D, _D, _D, _I, _P]),
+    "mseg_ranger_step": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _D, _D, _D, _D, _I, _I, _I, _D, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),

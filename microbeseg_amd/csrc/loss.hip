@@ -214,10 +214,9 @@ __device__ __forceinline__ void adam_amsgrad_one(float& p, float g, float& m, fl
 
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v,
-                                                           float* __restrict__ vmax, size_t n, float lr, float beta1,
-                                                           float beta2, float eps, float bc1, float bc2_sqrt) {
-  const float step_size = lr / bc1;
-  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+                                                           float* __restrict__ vmax, size_t n, float step_size,
+                                                           float w1, float beta2, float w2, float eps,
+                                                           float bc2_sqrt) {
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)vmax)) & 15) == 0;
@@ -241,16 +240,19 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
   }
 }
 
-extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
-                                      float beta1, float beta2, float eps, int step, void* stream) {
+extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, double lr,
+                                      double beta1, double beta2, double eps, int step, void* stream) {
   if (!p || !g || !m || !v || !vmax || n == 0 || step < 1) return MSEG_EINVAL;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  // python-float hyper-parameters arrive as doubles: torch evaluates 1 - beta, the bias corrections and lr / bc1 in
+  // double and rounds each scalar to fp32 once (1.f - 0.999f would be 4.7e-5 off the weight torch uses)
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256u * 16u) blocks = 256u * 16u;      // 16 workgroups of 4 waves per CU, grid-stride
   hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
-                     n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                     n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)sqrt(bc2));
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -262,8 +264,8 @@ extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float*
 __global__ __launch_bounds__(256) void ranger_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           float* __restrict__ slow, size_t n, int cols, float beta1,
-                                                          float beta2, float eps, float step_lr, int rectified,
-                                                          int do_gc, int lookahead, float alpha) {
+                                                          float w1, float beta2, float w2, float eps, float step_lr,
+                                                          int rectified, int do_gc, int lookahead, float alpha) {
   __shared__ double sh[4];
   const size_t base = (size_t)blockIdx.x * cols;
   size_t len = cols;
@@ -278,8 +280,8 @@ __global__ __launch_bounds__(256) void ranger_step_kernel(float* __restrict__ p,
   for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
     const size_t j = base + i;
     const float gi = g[j] - mean;
-    const float vi = v[j] * beta2 + (1.f - beta2) * (gi * gi);   // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-    const float mi = m[j] * beta1 + (1.f - beta1) * gi;          // exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    const float vi = v[j] * beta2 + w2 * (gi * gi);             // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float mi = m[j] * beta1 + w1 * gi;                    // exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
     v[j] = vi; m[j] = mi;
     const float upd = rectified ? mi / (sqrtf(vi) + eps) : mi;   // N_sma > threshold ? adaptive : plain momentum
     float pi = p[j] - step_lr * upd;
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(256) void ranger_step_kernel(float* __restrict__ p,
 }
 
 extern "C" int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, int rows,
-                                float beta1, float beta2, float eps, float step_lr, int rectified, int do_gc,
-                                int lookahead, float alpha, void* stream) {
+                                double beta1, double beta2, double eps, double step_lr, int rectified, int do_gc,
+                                int lookahead, double alpha, void* stream) {
   if (!p || !g || !m || !v || !slow || n == 0 || rows <= 0) return MSEG_EINVAL;
   int cols;
   unsigned blocks;
@@ -307,7 +309,8 @@ extern "C" int mseg_ranger_step(float* p, const float* g, float* m, float* v, fl
     blocks = (unsigned)((n + cols - 1) / cols);
   }
   hipLaunchKernelGGL(ranger_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, cols,
-                     beta1, beta2, eps, step_lr, rectified, do_gc, lookahead, alpha);
+                     (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)step_lr,
+                     rectified, do_gc, lookahead, (float)alpha);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

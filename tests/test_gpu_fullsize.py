@@ -135,13 +135,13 @@ def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
     """configs[2]: [64,1024] DU-Net, 320x320 crops, bf16 mode, against oracle/unet_ref.py BF16_RULE (the reference
     arithmetic with the build's rounding points) and against the fp32 reference arithmetic.
 
-    Through the 23 convolutions of the 5-level network bf16 rounding compounds: an operand whose fp32 value differs in the
-    last bits between two implementations rounds to the other bf16 neighbour (2^-8 relative), so two bf16 implementations
-    with IDENTICAL rounding points end ~sqrt(2) x the bf16-vs-fp32 distance apart (independent rounding noise), not 1e-4.
-    The own tolerance of this mode is therefore stated relative to what bf16 rounding itself does, d_ref = distance of
-    the bf16 oracle from the fp32 oracle (relative L2): the HIP path must be as close to fp32 as the model of its rounding
-    points (<= 1.25 d_ref), not further from that model than independent noise (<= 1.6 d_ref), really bf16 (>= 0.5
-    d_ref), and d_ref itself must be sane (< 3e-2 on the outputs).  Same rule per parameter gradient, with a 2e-2 floor.
+    Through the 23 convolutions of the 5-level network bf16 rounding compounds (measured on this random-init network:
+    the bf16 oracle ends 6.4e-2, relative L2, from the fp32 oracle), and an operand whose fp32 value differs in the last
+    bits between two implementations rounds to the other bf16 neighbour, so even identical rounding points do not give
+    1e-4 agreement.  The tolerance of this mode is therefore stated relative to what bf16 rounding itself does, d_ref =
+    distance of the bf16 oracle from the fp32 oracle: the HIP path must be as close to fp32 as the model of its rounding
+    points (<= 1.25 d_ref), clearly closer to that model than to fp32 (<= 0.75 d_ref; measured 0.35), really bf16
+    (>= 0.5 d_ref), and d_ref itself must be sane (< 0.15).  Same rule per parameter gradient, with a 2e-2 floor.
     ReLU decisions are replayed from the HIP path as in the fp32 test; their flip rate is bounded at 1e-2."""
     from microbeseg_amd.utils.unets import build_unet
     torch.manual_seed(78)
@@ -161,8 +161,8 @@ def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
         d_ref, d_model, d_fp32 = l2(a, b), l2(o, a), l2(o, b)
         print(f"output: bf16 oracle vs fp32 {d_ref:.2e}; HIP vs bf16 oracle {d_model:.2e}; HIP vs fp32 {d_fp32:.2e}; "
               f"max-norm HIP vs bf16 oracle {rel_err(o, a):.2e}")
-        assert 1e-4 < d_ref < 3e-2
-        assert 0.5 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 1.6 * d_ref
+        assert 1e-4 < d_ref < 0.15
+        assert 0.5 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 0.75 * d_ref
     # a bf16 ReLU decision flips wherever |z| is within bf16 rounding noise of 0: bounded at 1e-2 of the elements
     for m, z in zip(masks, trace):
         d = m != (z > 0)
@@ -178,7 +178,7 @@ def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
         d_model, d_fp32 = l2(p.grad.cpu(), p16[k].grad), l2(p.grad.cpu(), p32[k].grad)
         worst.append((d_fp32 / max(2e-2, 1.25 * d_ref), k, d_ref, d_model, d_fp32))
         assert d_fp32 < max(2e-2, 1.25 * d_ref), (k, d_ref, d_model, d_fp32)
-        assert d_model < max(2e-2, 1.6 * d_ref), (k, d_ref, d_model, d_fp32)
+        assert d_model < max(2e-2, 0.75 * d_ref), (k, d_ref, d_model, d_fp32)
     print("worst gradients (ratio, name, d_ref, d_model, d_fp32):", sorted(worst, reverse=True)[:3])
 
 
@@ -199,10 +199,6 @@ def test_config4_stack_2048_through_infer_worker(tmp_path, dev):
     from oracle import postproc_ref
     torch.manual_seed(3)
     net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
-    with torch.no_grad():      # random BN statistics would be all (0, 1): give the heads a usable output range
-        for d in (net.decoder1Conv[-1], net.decoder2Conv[-1]):
-            d.weight.mul_(4.0)
-            d.bias.fill_(0.3)
     worker = InferWorker(model=str(_write_checkpoint(tmp_path, net)), device="cuda:0", ths=(0.10, 0.45))
     rng = np.random.Generator(np.random.PCG64(2024))
     S = 2048
@@ -211,6 +207,17 @@ def test_config4_stack_2048_through_infer_worker(tmp_path, dev):
         cell, _ = synth.synth_prediction_maps(rng, S, S, 2500, rmin=5.0, rmax=13.0)
         frames.append(np.clip(cell * 50000 + rng.normal(0, 800, cell.shape), 0, 65535).astype(np.uint16))
     stack = np.stack(frames)
+    # an untrained network predicts no distance maps: pick the two thresholds from the distribution of its own output on
+    # frame 0 (~15 % of the pixels above th_cell, ~4 % seed pixels), so that the watershed has thousands of instances
+    f = stack[0]
+    with torch.no_grad():
+        x0 = torch.from_numpy((2 * (f.astype(np.float32) - f.min()) / (f.max() - f.min()) - 1)[None, None]).to(dev)
+        border, cell = worker.net(x0)
+        b = torch.tan(border[0, 0].clamp(0, 1) ** 2)
+        b = torch.where(b < 0.05, torch.zeros_like(b), b).clamp(0, 1)
+        sub = slice(None, None, 7)
+        worker.ths = [float(torch.quantile(cell[0, 0][sub, sub].flatten(), 0.85)),
+                      float(torch.quantile((cell[0, 0] - b)[sub, sub].flatten(), 0.96))]
     got = worker.infer_stack(stack)
     assert got.shape == stack.shape and got.dtype == np.uint16
     n_inst = []
@@ -220,12 +227,13 @@ def test_config4_stack_2048_through_infer_worker(tmp_path, dev):
         with torch.no_grad():
             border, cell = worker.net(torch.from_numpy(x[None, None]).to(dev))
         want = postproc_ref.distance_postprocessing(border[0, 0].cpu().numpy()[..., None],
-                                                    cell[0, 0].cpu().numpy()[..., None], 0.45, 0.10)
+                                                    cell[0, 0].cpu().numpy()[..., None], worker.ths[1], worker.ths[0])
         assert np.array_equal(got[t], want), f"frame {t}: {int((got[t] != want).sum())} pixels differ"
         one = worker.inference(f, f.min(), f.max(), [0, 0])
         assert np.array_equal(one, want)
         n_inst.append(int(want.max()))
-    print("instances per frame:", n_inst)
+    print("instances per frame:", n_inst, "thresholds (cell, seed):", worker.ths)
+    assert min(n_inst) > 500
 
 
 def test_config4_postprocessing_2048_synthetic_maps(dev):
