@@ -212,6 +212,21 @@ int mseg_ce_dice_fwd(const float* logits, const int64_t* labels, int N, int HW, 
 int mseg_ce_dice_bwd(const float* logits, const int64_t* labels, int N, int HW, int with_dice, const double* sums6,
                      double total_px, double dice_weight, const float* gscale_dev, float* grad, void* stream);
 
+/* ---- instance masks -> polygon ROIs --------------------------------------------------------
+ * Replaces get_indices_pandas + the per-instance cv2_countour loop (src/utils/hull_polygon.py:8-89, called from
+ * src/inference/infer.py:274-287) for a whole uint16 label image [H][W] (0 = background) on the device.
+ * mseg_polygons_find: start candidates (pixels whose W / NW / N / NE neighbours carry another label) into cand_px, and
+ *   per candidate its label (cand_id) and the length of the OUTER border that starts there (cand_len; 0 when the
+ *   candidate is not the raster-first pixel of an outer border).  *n_cand_dev = candidates found; if it exceeds
+ *   `capacity` the surplus was dropped and the caller repeats the call with larger arrays.
+ * mseg_polygons_trace: polygon k starts at pixel start_px[k] and owns points offsets[k] .. offsets[k+1]-1 of points_yx
+ *   ((row, col) int32 pairs, in the order cv2.findContours(..., CHAIN_APPROX_NONE) lists an outer border: from the
+ *   top-left-most pixel DOWN the left side, every visited pixel, 8-connected foreground).                              */
+int mseg_polygons_find(const uint16_t* labels, int H, int W, int32_t* cand_px, int32_t* cand_id, int32_t* cand_len,
+                       int capacity, int32_t* n_cand_dev, void* stream);
+int mseg_polygons_trace(const uint16_t* labels, int H, int W, const int32_t* start_px, const int64_t* offsets, int n_poly,
+                        int32_t* points_yx, void* stream);
+
 /* ---- fused optimizers (train.py:379-428, ranger2020.py:101-208) --------------------------------------------- */
 /* torch.optim.Adam(amsgrad=True, weight_decay=0) on ONE flat range (train.py:380-385): p, g, exp_avg, exp_avg_sq,
  * max_exp_avg_sq of n elements; `step` = 1-based step count.  Hyper-parameters are doubles (python floats): 1 - beta,

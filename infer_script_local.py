@@ -43,6 +43,9 @@ def main():
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                         help='[extension] bf16 = bf16 matrix-core inputs for the network (faster; masks are no longer '
                              'guaranteed identical to the fp32 reference arithmetic)')
+    parser.add_argument('--rois', default=False, action='store_true',
+                        help='[extension] also write <mask file stem>_rois.json: one polygon ROI per cell and frame, the '
+                             'records the OMERO route of infer_script.py uploads (traced on the device)')
     args = parser.parse_args()
 
     imgs_path = Path(args.img_dir)
@@ -76,6 +79,11 @@ def main():
         print(f'Process {img_id.stem} (channel: {args.channel})')
         results = worker.infer_stack(frames)
         tiff.imwrite(str(out_file), np.squeeze(results))
+        if args.rois:
+            import json
+            rois = [roi for t in range(len(results)) for roi in worker.polygon_rois(results[t], t)]
+            with open(out_file.with_name(out_file.stem + '_rois.json'), 'w', encoding='utf-8') as f:
+                json.dump({'image': img_id.name, 'channel': args.channel, 'rois': rois}, f)
     print('--- Finished ---')
 
 

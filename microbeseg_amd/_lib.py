@@ -114,6 +114,8 @@ SIGNATURES = {
     "mseg_eval_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_eval_relabel": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mseg_eval_pair_counts": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "mseg_polygons_find": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "mseg_polygons_trace": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "mseg_version": (_I, []),
     "mseg_strerror": (C.c_char_p, [_I]),
     "mseg_last_hip_error": (_I, []),

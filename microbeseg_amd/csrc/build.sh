@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libmseg_hip.so
-SRCS="igemm.hip wgrad.hip first.hip norm.hip head.hip loss.hip augment.hip labels.hip api_misc.hip"
+SRCS="igemm.hip wgrad.hip first.hip norm.hip head.hip loss.hip augment.hip labels.hip polygons.hip api_misc.hip"
 [ -f postproc.hip ] && SRCS="$SRCS postproc.hip"
 mkdir -p ../_build
 OBJS=""

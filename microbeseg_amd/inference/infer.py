@@ -201,6 +201,39 @@ class InferWorker(QObject):
                 finish(pending.pop(0))
         return results
 
+    # -- what follows the prediction on the reference's routes (infer.py:265-291 upload, :320-322 local save) -------------
+    STROKE_COLOR = int.from_bytes([255, 255, 0, 255], byteorder='big', signed=True)     # yellow, opaque (infer.py:271-272)
+
+    def polygon_rois(self, prediction, frame=0):
+        """ One polygon ROI per cell of a predicted frame, as plain records with the fields the reference sets on its
+        ``omero.model.PolygonI`` objects (theZ, theT, theC, fillColor, strokeColor, points = "x,y x,y ... ").  The
+        contours of ALL instances are traced on the device in two launches (utils/hull_polygon.py) instead of one
+        ``cv2.findContours`` call per instance. """
+        from ..utils.hull_polygon import label_polygons, points_string
+        rois = []
+        if np.max(prediction) > 0:
+            for polygons in label_polygons(prediction).values():
+                for polygon in polygons:
+                    rois.append({'theZ': 0, 'theT': int(frame), 'theC': int(self.channel), 'fillColor': 0,
+                                 'strokeColor': self.STROKE_COLOR, 'points': points_string(polygon)})
+        return rois
+
+    def save_results(self, results_array, image_name, result_path=None, with_rois=False):
+        """ ``<result_path>/<image stem>_channel<c>.tif`` (uint16 [T, H, W], the reference's local-save route) and, with
+        ``with_rois``, ``<...>_rois.json``: the polygon ROIs per frame that the upload route would send to OMERO. """
+        from ..utils import tiffio as tiff
+        result_path = Path(self.inference_path if result_path is None else result_path)
+        result_path.mkdir(parents=True, exist_ok=True)
+        stem = Path(image_name).stem
+        target = result_path / f"{stem}_channel{self.channel}.tif"
+        tiff.imwrite(str(target), results_array)
+        if with_rois:
+            frames = results_array if results_array.ndim == 3 else results_array[None]
+            rois = [roi for t, frame in enumerate(frames) for roi in self.polygon_rois(frame, t)]
+            with open(result_path / f"{stem}_channel{self.channel}_rois.json", 'w', encoding='utf-8') as f:
+                json.dump({'image': str(image_name), 'channel': int(self.channel), 'rois': rois}, f)
+        return target
+
     @pyqtSlot()
     def inference_finished(self):
         self.finished.emit()

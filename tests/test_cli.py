@@ -30,7 +30,16 @@ def test_train_then_infer_cli(tmp_path):
     tiffio.imwrite(str(imgs / "movie.tif"), stack)
     res = tmp_path / "results"
     r = subprocess.run([sys.executable, str(ROOT / "infer_script_local.py"), "-i", str(imgs), "-m", str(model), "-r",
-                        str(res)], capture_output=True, text=True, timeout=600)
+                        str(res), "--rois"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = tiffio.imread(str(res / "mask_movie_channel0.tif"))
     assert out.shape == (5, 128, 128) and out.dtype == np.uint16
+    # --rois: one polygon record per instance and frame (the OMERO route's payload, infer.py:265-287)
+    import json
+    rois = json.load(open(res / "mask_movie_channel0_rois.json"))["rois"]
+    assert len(rois) == sum(len(np.unique(f)) - 1 for f in out)
+    for roi in rois[:20]:
+        pts = [tuple(int(v) for v in p.split(",")) for p in roi["points"].split()]
+        frame = out[roi["theT"]]
+        ids = {int(frame[y, x]) for x, y in pts}
+        assert len(ids) == 1 and 0 not in ids and roi["theC"] == 0 and roi["strokeColor"] == -65281
