@@ -43,6 +43,9 @@ def main():
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                         help='[extension] bf16 = bf16 matrix-core inputs for the network (faster; masks are no longer '
                              'guaranteed identical to the fp32 reference arithmetic)')
+    parser.add_argument('--sliding_window', default=False, action='store_true',
+                        help='[extension] tiled inference (2048 px tiles + 128 px halo; same prediction as whole-frame '
+                             'inference for the BatchNorm models training produces); lifts the 8192 px frame limit')
     parser.add_argument('--rois', default=False, action='store_true',
                         help='[extension] also write <mask file stem>_rois.json: one polygon ROI per cell and frame, the '
                              'records the OMERO route of infer_script.py uploads (traced on the device)')
@@ -63,7 +66,8 @@ def main():
     if len(file_ids) == 0:
         print('No files found')
         return
-    worker = InferWorker(model=args.model, device=args.device, ths=args.thresholds, channel=args.channel)
+    worker = InferWorker(model=args.model, device=args.device, ths=args.thresholds, channel=args.channel,
+                         sliding_window=args.sliding_window)
     worker.precision = args.precision
     worker.text_output.connect(print)
     torch.set_grad_enabled(False)

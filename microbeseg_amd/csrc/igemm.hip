@@ -99,6 +99,19 @@ __device__ __forceinline__ bool tap_coord(const TapGeom& g, const RowInfo& r, in
   return (r.n >= 0) & (((ty | tx) & g.sh) == 0) & (iy >= 0) & (iy < g.Hi) & (ix >= 0) & (ix < g.Wi);
 }
 
+// Gather kernels: first source pixel a tile of BM consecutive GEMM rows can touch (64-bit, wave-uniform).  The buffer
+// descriptors of a tile are based there, so the 32-bit offsets of its loads only span the few image rows the tile reads —
+// operands of any size (a 4096 x 4096 x 128 level-1 tensor is 8.6 GB) stay on the fast kernels.  Source pixels grow
+// monotonically with the GEMM row inside a tile (linear M-order, and parity M-order within one parity class), so the
+// first row's tap (0, 0), minus the reach of the mirrored taps of a transposed convolution, is a lower bound.
+__device__ __forceinline__ long long tile_base_pixel(const MsegIgemm& p, const TapGeom& g, int m0, int M) {
+  const RowInfo r = decode_row(p, m0, M);
+  const int iy0 = (r.oy * g.sm - g.dir * g.pad) >> g.sh, ix0 = (r.ox * g.sm - g.dir * g.pad) >> g.sh;
+  long long px = ((long long)r.n * p.Hi + iy0) * p.Wi + ix0;
+  if (g.dir < 0) px -= (long long)((p.KH - 1) >> g.sh) * p.Wi + ((p.KW - 1) >> g.sh);
+  return px;
+}
+
 // ---- shared epilogue ---------------------------------------------------------------------------------------------
 template <typename Cfg, typename AccT>
 __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, int m0, int n0, int wm, int wn,
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 //   * scale/shift tables are fetched once per 32-channel chunk, not once per tap;
 //   * operands without transform (all dgrad launches) are committed to LDS untouched.
 // Preconditions (checked on the host, otherwise the generic kernel above runs): CONV mode, stride-1 TCONV, or stride-2
-// TCONV in parity M-order with parity classes that are whole tiles; every operand < 2 GiB; the concat boundary C0 a
+// TCONV in parity M-order with parity classes that are whole tiles; a tile's source rows < 2 GiB; the concat boundary C0 a
 // multiple of 32 (wave-uniform source selection).
 // TR: 0 = plain operand, 1 = none/ReLU + affine, 2 = any activation + affine.
 template <int BM, int BN, int TR, bool PER_SAMPLE>
@@ -496,6 +509,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
 
   // ---- per-row geometry, once per tile ------------------------------------------------------------------------
   const TapGeom geom = make_geom(p);
+  const long long tile_px = tile_base_pixel(p, geom, m0, M);
   int pix0[Cfg::AROWS];            // source pixel index of tap (0,0); meaningful only where a tap is live
   int rown[Cfg::AROWS];            // image index (per-sample tables)
   unsigned vmask[Cfg::AROWS];      // bit t set <=> tap t of this row reads a real source pixel
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
     // source coordinate of a live tap = (o * sm - dir * pad) >> sh  +  dir * (k >> sh): linear in the tap for every
     // row of the tile (stride-2 TCONV: the parity M-order makes the live-tap set tile-uniform, see `taplist`)
     const int iy0 = (r.oy * geom.sm - geom.dir * geom.pad) >> geom.sh, ix0 = (r.ox * geom.sm - geom.dir * geom.pad) >> geom.sh;
-    pix0[i] = (r.n * p.Hi + iy0) * p.Wi + ix0;
+    pix0[i] = (int)(((long long)r.n * p.Hi + iy0) * p.Wi + ix0 - tile_px);   // relative to the tile's descriptor base
     rown[i] = r.n < 0 ? 0 : r.n;
     unsigned mk = 0u;
     for (int t = 0; t < T; ++t) {
@@ -526,14 +540,16 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
 
   const int nchunks = (p.Cin + KC - 1) / KC;
   const int C0 = p.src[0].C;
-  const unsigned OOB = 0x80000000u;   // >= num_records of every descriptor (operands are < 2 GiB)
+  const unsigned OOB = 0x80000000u;   // >= num_records of every descriptor
 
   // wave-uniform buffer descriptors (kernarg-derived only)
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0,
-                                                                        p.NB * p.Hi * p.Wi * p.src[0].C * 4, 0x00020000);
+  // based at the tile's first source pixel; every load is masked by vmask (dead rows use OOB), so the record count only
+  // has to exceed the tile's span (host-checked to stay below 2 GiB)
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src[0].ptr + tile_px * p.src[0].C), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr), 0,
-      p.NB * p.Hi * p.Wi * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * 4, 0x00020000);
+      const_cast<float*>((p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + tile_px * (p.nsrc > 1 ? p.src[1].C : p.src[0].C)), 0,
+      0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         T * p.Npad * p.Kpad * 4, 0x00020000);
   unsigned wvoff[Cfg::BROWS];
@@ -743,6 +759,11 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   const int trem = tile_m - img * (tiles_x * tiles_y);
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  // buffer descriptors span only the row band of this tile's halo (image rows band0 .. band0 + band_rows - 1): 32-bit
+  // offsets then never see more than (TH + 2) x W pixels, so neither the batch size nor the FRAME size is limited
+  // (8192 x 8192 frames, the reference's largest tested shape, stay on this kernel)
+  const int band0 = oy0 > 0 ? oy0 - 1 : 0;
+  const int band_rows = (oy0 + TH + 1 < H ? oy0 + TH + 1 : H) - band0;
   const bool conv = p.mode == MSEG_MODE_CONV;       // TCONV (data gradient) = the same halo with the taps mirrored
 
   // ---- halo entries of this thread: rows hrow = srow + 32 j, channel quad scol ----------------------------------
@@ -754,7 +775,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-    hpix[j] = iy * W + ix;                           // pixel index inside the image (the descriptors are per image)
+    hpix[j] = (iy - band0) * W + ix;                 // pixel index inside the tile's row band (see the descriptors)
     hvalid |= (unsigned)ok << j;
   }
   // per-lane LDS row of the MFMA A rows (tile pixel -> halo coordinates of tap (0,0))
@@ -776,15 +797,13 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const MsegIgemm p, i
   const int nchunks = (p.Cin + KC - 1) / KC;
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
-  // buffer descriptors of THIS tile's image: 32-bit offsets then only have to span one image (< 2 GiB, host-checked),
-  // whatever the batch size — the tensor as a whole may be far larger
   const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
-  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
-  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const float* const base0 = p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
-                                                                        H * W * p.src[0].C * 4, 0x00020000);
+                                                                        band_rows * W * p.src[0].C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
-                                                                        H * W * C1 * 4, 0x00020000);
+                                                                        band_rows * W * C1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 4, 0x00020000);
   unsigned wvoff[Cfg::BROWS];
@@ -961,6 +980,11 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   const int trem = tile_m - img * (tiles_x * tiles_y);
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  // buffer descriptors span only the row band of this tile's halo (image rows band0 .. band0 + band_rows - 1): 32-bit
+  // offsets then never see more than (TH + 2) x W pixels, so neither the batch size nor the FRAME size is limited
+  // (8192 x 8192 frames, the reference's largest tested shape, stay on this kernel)
+  const int band0 = oy0 > 0 ? oy0 - 1 : 0;
+  const int band_rows = (oy0 + TH + 1 < H ? oy0 + TH + 1 : H) - band0;
   const bool conv = p.mode == MSEG_MODE_CONV;
 
   int hpix[HL];
@@ -971,7 +995,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-    hpix[j] = iy * W + ix;
+    hpix[j] = (iy - band0) * W + ix;
     hvalid |= (unsigned)ok << j;
   }
   int abase[Cfg::MB];
@@ -993,12 +1017,12 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
   const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
-  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
-  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const float* const base0 = p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
-                                                                        H * W * p.src[0].C * 4, 0x00020000);
+                                                                        band_rows * W * p.src[0].C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
-                                                                        H * W * C1 * 4, 0x00020000);
+                                                                        band_rows * W * C1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 2, 0x00020000);
   const bool bact = brow < BN;
@@ -1171,6 +1195,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   const int trem = tile_m - img * (tiles_x * tiles_y);
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  // buffer descriptors span only the row band of this tile's halo (image rows band0 .. band0 + band_rows - 1): 32-bit
+  // offsets then never see more than (TH + 2) x W pixels, so neither the batch size nor the FRAME size is limited
+  // (8192 x 8192 frames, the reference's largest tested shape, stay on this kernel)
+  const int band0 = oy0 > 0 ? oy0 - 1 : 0;
+  const int band_rows = (oy0 + TH + 1 < H ? oy0 + TH + 1 : H) - band0;
   const bool conv = p.mode == MSEG_MODE_CONV;
 
   int hpix[HL];
@@ -1181,7 +1210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-    hpix[j] = iy * W + ix;
+    hpix[j] = (iy - band0) * W + ix;
     hvalid |= (unsigned)ok << j;
   }
   int abase[Cfg::MB];
@@ -1203,12 +1232,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
   const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
-  const float* const base0 = p.src[0].ptr + (size_t)img * H * W * p.src[0].C;
-  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + (size_t)img * H * W * C1;
+  const float* const base0 = p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C;
+  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
-                                                                        H * W * p.src[0].C * 4, 0x00020000);
+                                                                        band_rows * W * p.src[0].C * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
-                                                                        H * W * C1 * 4, 0x00020000);
+                                                                        band_rows * W * C1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 2, 0x00020000);
   const unsigned wvoff = ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u;
@@ -1382,6 +1411,7 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
   const int brow = tid >> 2, bcol = tid & 3;
 
   const TapGeom geom = make_geom(p);
+  const long long tile_px = tile_base_pixel(p, geom, m0, M);
   int pix0[Cfg::AROWS];
   int rown[Cfg::AROWS];
   unsigned vmask[Cfg::AROWS];
@@ -1389,7 +1419,7 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
   for (int i = 0; i < Cfg::AROWS; ++i) {
     const RowInfo r = decode_row(p, m0 + srow + 32 * i, M);
     const int iy0 = (r.oy * geom.sm - geom.dir * geom.pad) >> geom.sh, ix0 = (r.ox * geom.sm - geom.dir * geom.pad) >> geom.sh;
-    pix0[i] = (r.n * p.Hi + iy0) * p.Wi + ix0;
+    pix0[i] = (int)(((long long)r.n * p.Hi + iy0) * p.Wi + ix0 - tile_px);   // relative to the tile's descriptor base
     rown[i] = r.n < 0 ? 0 : r.n;
     unsigned mk = 0u;
     for (int t = 0; t < T; ++t) {
@@ -1411,11 +1441,13 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
   const int nchunks = (p.Cin + KC - 1) / KC;
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src[0].ptr), 0,
-                                                                        p.NB * p.Hi * p.Wi * p.src[0].C * 4, 0x00020000);
+  // based at the tile's first source pixel; every load is masked by vmask (dead rows use OOB), so the record count only
+  // has to exceed the tile's span (host-checked to stay below 2 GiB)
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.src[0].ptr + tile_px * p.src[0].C), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr), 0,
-      p.NB * p.Hi * p.Wi * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * 4, 0x00020000);
+      const_cast<float*>((p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + tile_px * (p.nsrc > 1 ? p.src[1].C : p.src[0].C)), 0,
+      0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         T * p.Npad * p.Kpad * 2, 0x00020000);
   unsigned wvoff[BPASS];
@@ -1682,13 +1714,14 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long tiles = ((M + BMv - 1) / BMv) * ((p.Ngemm + BNv - 1) / BNv);
   if (tiles > 0x7fffffffLL) return MSEG_EINVAL;
   const dim3 grid((unsigned)tiles), block(256);
-  // fast path preconditions (see igemm_fast_kernel): 32-bit buffer offsets over the WHOLE operand (< 2 GiB)
+  // fast path preconditions (see igemm_fast_kernel): 32-bit buffer offsets over the source rows of ONE TILE (< 2 GiB)
   bool fast = (p.mode == MSEG_MODE_CONV) || (p.stride == 1) ||
               (p.morder == MSEG_MORDER_PARITY && (M % (4 * BMv)) == 0);   // s2 dgrad: parity-uniform tiles
-  bool plain = true, image_fits = true;
+  bool plain = true, band_fits = true;
   for (int i = 0; i < p.nsrc; ++i) {
-    if ((long long)p.NB * p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) fast = false;
-    if ((long long)p.Hi * p.Wi * p.src[i].C * 4 >= 0x80000000LL) image_fits = false;
+    // gather kernels: descriptors per tile; the span of a tile = the source rows 128 consecutive output pixels read
+    if (((128LL / p.Wo + 3) * p.stride + p.KH) * p.Wi * p.src[i].C * 4 >= 0x7ffffff0LL) fast = false;
+    if (34LL * p.Wi * p.src[i].C * 4 >= 0x80000000LL) band_fits = false;   // halo row band: at most 32 + 2 rows
     if (p.src[i].act != MSEG_ACT_NONE || p.src[i].scale) plain = false;
   }
   bool common = true;                                                // shared by the fast and the halo kernel
@@ -1696,11 +1729,12 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   if (p.KH > 4 || p.KW > 4) common = false;                          // packed tap list: 2 bits per tap coordinate
   if (p.nsrc > 1 && (p.src[0].C % KC)) common = false;
   fast = fast && common;
-  // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient).  Its descriptors are
-  // per image, so only ONE IMAGE of each operand has to stay below 2 GiB: any batch size keeps the fast path.
+  // halo kernel: 3x3, stride 1, pad 1 (forward of every ConvBlock conv and its data gradient).  Its descriptors span the
+  // row band of a tile's halo, so only (TH + 2) image rows of an operand have to stay below 2 GiB: any batch size and any
+  // frame size (the reference pads frames up to 8192 x 8192, utils.py:137-138) keep the fast path.
   int tw_log2 = 6;
   long long htiles = 0;
-  if (common && image_fits && halo_geometry(p, BNv, &tw_log2, &htiles) && htiles <= 0x7fffffffLL) {
+  if (common && band_fits && halo_geometry(p, BNv, &tw_log2, &htiles) && htiles <= 0x7fffffffLL) {
     const int tr = plain ? 0 : (generic ? 2 : 1);
     // split-K over the input-channel chunks when the tiles would leave most of the chip idle (small batches, deep levels)
     int cps = 0;

@@ -121,7 +121,19 @@ def _tr_of(s):
     return 1 if s.act in (ACT["none"], ACT["relu"]) else 2
 
 
-def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False, parity_tiles=False):
+def _tile_span_ok(srcs, Hi, Wi, Ho, Wo, KH, stride):
+    """mirror of the launcher: the source rows one 128-pixel tile of a gather kernel reads must stay below 2 GiB (its
+    buffer descriptors are based per tile, so the size of the whole operand does not matter)"""
+    return all(((128 // Wo + 3) * stride + KH) * Wi * s.C * 4 < 0x7ffffff0 for s in srcs)
+
+
+def _halo_band_ok(srcs, Wi):
+    """mirror of the launcher: the halo kernels' descriptors span the <= 34 image rows of a tile's halo"""
+    return all(34 * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+
+
+def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False, parity_tiles=False, Ho=None,
+                       Wo=None):
     """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
     appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
     bn = 128 if Ngemm > 64 else 64
@@ -129,9 +141,9 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok
     generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in srcs)
     common = KH <= 4 and KW <= 4 and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
     fast = common and (mode == MODE_CONV or stride == 1 or parity_tiles) and \
-        all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
-    # the halo kernel's buffer descriptors are per image: only one image of an operand has to stay below 2 GiB
-    if common and halo_ok and all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs):
+        _tile_span_ok(srcs, Hi, Wi, Ho or Hi, Wo or Wi, KH, stride)
+    # the halo kernel's buffer descriptors span a tile's row band: frames and batches of any size
+    if common and halo_ok and _halo_band_ok(srcs, Wi):
         tr = max(_tr_of(s) for s in srcs)
         return "igemm_halo_kernel<%d, %d>" % (bn, 0 if tr == 0 else (2 if generic else 1))
     if fast:
@@ -341,11 +353,10 @@ def _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, mo
     if not common:
         return None
     if (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi and Wo == Wi and epi == EPI_PLAIN and
-            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32) and
-            all(Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)):
+            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32) and _halo_band_ok(srcs, Wi)):
         return "halo"
     fast = (mode == MODE_CONV or stride == 1 or (morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)) and \
-        all(NB * Hi * Wi * s.C * 4 < 2 ** 31 for s in srcs)
+        _tile_span_ok(srcs, Hi, Wi, Ho, Wo, KH, stride)
     return "fast" if fast else None
 
 
@@ -389,7 +400,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
                               halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
                                        and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
-                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0))
+                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0), Ho=Ho, Wo=Wo)
     if bf16:
         name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
             "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")

@@ -59,6 +59,8 @@ class InferWorker(QObject):
     # ~3x faster; predictions differ from the fp32 reference arithmetic in the third digit, so masks are no longer
     # guaranteed bit-identical to the reference's — opt-in only, the default is the reference's fp32
     precision = "fp32"
+    # [extension] edge length of the tiles of sliding-window inference (``sliding_window=True``; inference/tiling.py)
+    tile_size = 2048
 
     def __init__(self, img_id_list=None, inference_path=None, user=None, pw=None, host=None, port=None, group_id=None,
                  model=None, device='cuda:0', ths=(0.10, 0.45), channel=0, upload=True, overwrite=True,
@@ -73,7 +75,9 @@ class InferWorker(QObject):
         self.channel = channel
         self.upload = upload
         self.overwrite = overwrite
-        self.sliding_window = sliding_window   # stored, never read — exactly like the reference (infer.py:60,76)
+        # the reference stores this flag and never reads it (infer.py:60,76); here it switches on tiled inference, whose
+        # prediction equals whole-frame inference (inference/tiling.py) and which lifts the 8192-px limit of the padding
+        self.sliding_window = sliding_window
         self.print_output = print_output
         self.net, self.model_settings = (None, None)
         if model is not None:
@@ -83,6 +87,16 @@ class InferWorker(QObject):
         """The reference pulls planes from an OMERO server here (infer.py:113-326): not part of this build."""
         raise RuntimeError("InferWorker.start_inference needs the OMERO stack (omero-py), which is outside the "
                            "MI355X hot path; use infer_stack()/inference() or infer_script_local.py")
+
+    def pad_frame(self, img_frame, pad_val):
+        """top / left padding of a frame up to the next tested shape, like the reference (utils.py:124-163).  Frames beyond
+        8192 px raise 'Image too big to pad. Use sliding windows' there; with ``sliding_window`` they are padded to the
+        16-px grid of the network instead (smaller frames keep the reference's padding, so that tiled and whole-frame
+        inference see the same input)."""
+        if self.sliding_window and max(img_frame.shape[:2]) > 8192:
+            from .tiling import pad_to_grid
+            return pad_to_grid(img_frame, pad_val)
+        return zero_pad_model_input(img_frame, pad_val=pad_val)
 
     def inference(self, img, min_val, max_val, pads):
         """ Predict one (already padded) frame.
@@ -107,6 +121,9 @@ class InferWorker(QObject):
         """network forward of one padded frame; None (after the reference's message) if it does not fit in memory"""
         try:
             with engine.precision_scope(self.precision):
+                if self.sliding_window:
+                    from .tiling import tiled_forward
+                    return tiled_forward(self.net, img_batch.to(self.device), tile=self.tile_size)
                 return self.net(img_batch.to(self.device))
         except (RuntimeError, MemoryError) as err:
             if not is_out_of_memory(err):
@@ -150,7 +167,7 @@ class InferWorker(QObject):
                     break
                 img_frame = np.copy(img[frame])
                 frame_min, frame_max = np.min(img_frame), np.max(img_frame)
-                img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
+                img_frame, pads = self.pad_frame(img_frame, frame_min)
                 results[frame] = self.inference(img_frame, frame_min, frame_max, pads)
                 self.progress.emit(int(100 * (frame + 1) / len(img)))
             return results
@@ -172,7 +189,7 @@ class InferWorker(QObject):
                     break
                 img_frame = np.copy(img[frame])
                 frame_min, frame_max = np.min(img_frame), np.max(img_frame)
-                img_frame, pads = zero_pad_model_input(img_frame, pad_val=frame_min)
+                img_frame, pads = self.pad_frame(img_frame, frame_min)
                 img_batch = 2 * (img_frame.astype(np.float32) - frame_min) / (frame_max - frame_min) - 1
                 img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
                 pred = self._forward(img_batch)

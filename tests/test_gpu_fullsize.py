@@ -250,11 +250,15 @@ def test_config4_postprocessing_2048_synthetic_maps(dev):
     assert int(n) == int(want.max()) and int(n) > 1500
 
 
-def test_frame_3200_equals_overlapping_halves(dev):
-    """A 3200x3200 frame (one of the reference's tested shapes, utils.py:137-138): its level-0 tensor is 2.6 GB, beyond
-    32-bit buffer offsets.  In eval mode (BatchNorm = per-channel affine, no global statistics) the whole-frame output
-    must equal the output of the same network on two halves cut with a halo wider than the receptive field
-    (107 px for 5 levels; 128 keeps the 16-px level alignment): top rows [0, 1728) and bottom rows [1472, 3200)."""
+@pytest.mark.parametrize("S", [3200, 4096])
+def test_large_frame_equals_overlapping_halves(S, dev):
+    """Frames whose tensors exceed 32-bit byte offsets (3200 and 4096 px are tested shapes of the reference,
+    utils.py:137-138): level-0 tensors of 2.6 / 4.3 GB, a level-1 tensor of 2.1 GB at 4096 px.  Every convolution must
+    stay on the fast kernels (buffer descriptors based per tile row band / per tile, csrc/igemm.hip) — the generic
+    gather kernel is 4-5x slower — and, in eval mode (BatchNorm = per-channel affine, no global statistics), the
+    whole-frame output must equal the output of the same network on two halves cut with a halo wider than the
+    receptive field (107 px for 5 levels; 128 keeps the 16-px level alignment)."""
+    from microbeseg_amd import engine
     from microbeseg_amd.utils.unets import build_unet
     torch.manual_seed(4)
     net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=FILTERS)
@@ -265,12 +269,65 @@ def test_frame_3200_equals_overlapping_halves(dev):
                 m.running_var.uniform_(0.5, 1.5)
     net.eval()
     g = torch.Generator().manual_seed(8)
-    x = (torch.rand(1, 1, 3200, 3200, generator=g) * 2 - 1).to(dev)
+    x = (torch.rand(1, 1, S, S, generator=g) * 2 - 1).to(dev)
+    half = S // 2
+    timer = engine.KernelTimer()
     with torch.no_grad():
-        full = [o.cpu() for o in net(x)]
-        top = [o.cpu() for o in net(x[:, :, :1728].contiguous())]
-        bot = [o.cpu() for o in net(x[:, :, 1472:].contiguous())]
+        engine.set_kernel_timer(timer)
+        try:
+            full = [o.cpu() for o in net(x)]
+        finally:
+            engine.set_kernel_timer(None)
+        top = [o.cpu() for o in net(x[:, :, :half + 128].contiguous())]
+        bot = [o.cpu() for o in net(x[:, :, half - 128:].contiguous())]
+    names = set(timer.summary())
+    assert not any(n.startswith("igemm_kernel<") for n in names), names        # nothing fell back to the generic kernel
+    assert any(n.startswith("igemm_halo_kernel<") for n in names) and any(n.startswith("igemm_fast_kernel<") for n in names)
     for f, a, b in zip(full, top, bot):
         assert torch.isfinite(f).all()
-        assert rel_err(a[:, :, :1600], f[:, :, :1600]) < 1e-5
-        assert rel_err(b[:, :, 128:], f[:, :, 1600:]) < 1e-5
+        assert rel_err(a[:, :, :half], f[:, :, :half]) < 1e-5
+        assert rel_err(b[:, :, 128:], f[:, :, half:]) < 1e-5
+
+
+def test_sliding_window_inference_equals_whole_frame(tmp_path, dev):
+    """[extension] InferWorker(sliding_window=True): tiles of 512 px + 128 px halo through a 5-level BatchNorm net give the
+    whole-frame prediction (1e-5) and the identical instance mask on an odd-sized frame; a GroupNorm model is refused."""
+    from microbeseg_amd.inference.infer import InferWorker
+    from microbeseg_amd.inference.tiling import tiled_forward
+    from microbeseg_amd.utils import synth
+    from microbeseg_amd.utils.unets import build_unet
+    flt = (16, 256)
+    torch.manual_seed(6)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=flt)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    torch.save(net.state_dict(), str(tmp_path / "distance_model_00.pth"))
+    with open(tmp_path / "distance_model_00.json", "w") as f:
+        json.dump({"architecture": ["DU", "conv", "relu", "bn", list(flt)], "label_type": "distance"}, f)
+    rng = np.random.Generator(np.random.PCG64(77))
+    cell, _ = synth.synth_prediction_maps(rng, 1100, 1500, 900, rmin=5.0, rmax=13.0)
+    frame = np.clip(cell * 50000 + rng.normal(0, 800, cell.shape), 0, 65535).astype(np.uint16)
+    whole = InferWorker(model=str(tmp_path / "distance_model_00"), device="cuda:0")
+    tiled = InferWorker(model=str(tmp_path / "distance_model_00"), device="cuda:0", sliding_window=True)
+    tiled.tile_size = 512
+    padded, pads = whole.pad_frame(frame, frame.min())
+    assert padded.shape == (1280, 1600) and tiled.pad_frame(frame, frame.min())[1] == pads
+    x = torch.from_numpy((2 * (padded.astype(np.float32) - frame.min()) / (frame.max() - frame.min()) - 1)[None, None])
+    with torch.no_grad():
+        a, b = whole._forward(x), tiled._forward(x)
+    for u, v in zip(a, b):
+        assert rel_err(v.cpu(), u.cpu()) < 1e-5
+    # thresholds from the prediction itself (untrained net), then the complete path on both workers
+    c = a[1][0, 0, pads[0]:, pads[1]:]
+    ths = [float(torch.quantile(c[::5, ::5].flatten(), 0.85)), float(torch.quantile(c[::5, ::5].flatten(), 0.95))]
+    whole.ths = tiled.ths = ths
+    m_whole = whole.infer_stack(frame[None])
+    m_tiled = tiled.infer_stack(frame[None])
+    assert m_whole.shape == (1, 1100, 1500) and int(m_whole.max()) > 50
+    assert np.array_equal(m_whole, m_tiled)
+    gn = build_unet("DU", "relu", "conv", "gn", dev, 1, ch_out=1, filters=flt).eval()
+    with pytest.raises(RuntimeError, match="BatchNorm"):
+        tiled_forward(gn, x.to(dev), tile=512)
