@@ -106,44 +106,91 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(args, filters):
-    """The reference's CPU path (torch CPU fp32, all host cores) restated by oracle/unet_ref.py: same architecture,
-    loss and optimizer, batch 2, a few steps.  Baseline only — not what is shipped or measured as `value`."""
+def _cpu_train_steps(arch, act, norm, filters, size, batch, budget_s, max_steps, cores):
+    """a few training steps of one configuration through oracle/unet_ref.py on the host cores -> (crops/s, steps)"""
     from oracle import unet_ref
     from microbeseg_amd.utils.unets import build_unet
-    cores = min(host_cores(), 64)
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
-    holder = build_unet(args.arch, args.act, "conv", args.norm, "cpu", 1, ch_out=3 if args.arch == "U" else 1,
-                        filters=filters)
+    holder = build_unet(arch, act, "conv", norm, "cpu", 1, ch_out=3 if arch == "U" else 1, filters=filters)
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
               else v.detach().clone()) for k, v in holder.state_dict().items()}
-    plist = [v for v in sd.values() if v.requires_grad]
-    opt = torch.optim.Adam(plist, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
-    b = 2
-    img, l1, l2 = synthetic_batch(b, args.size, args.arch, 99, "cpu")
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=8e-4, betas=(0.9, 0.999), eps=1e-8,
+                           amsgrad=True)
+    img, l1, l2 = synthetic_batch(batch, size, arch, 99, "cpu")
 
-    def step():
+    def step(train=True):
         opt.zero_grad()
-        out = unet_ref.unet_forward(sd, img, args.arch, args.act, args.norm, filters, training=True,
-                                    update_running_stats=True)
-        if args.arch == "DU":
-            loss = unet_ref.regression_loss(out[0], l1) + unet_ref.regression_loss(out[1], l2)
-        else:
-            loss = unet_ref.ce_dice(out, l1)
-        loss.backward()
-        opt.step()
+        with torch.set_grad_enabled(train):
+            out = unet_ref.unet_forward(sd, img, arch, act, norm, filters, training=train, update_running_stats=train)
+            if arch == "DU":
+                loss = unet_ref.regression_loss(out[0], l1) + unet_ref.regression_loss(out[1], l2)
+            else:
+                loss = unet_ref.ce_dice(out, l1)
+            if train:
+                loss.backward()
+                opt.step()
         return loss.item()
 
     step()  # warm-up
     n, t0 = 0, time.perf_counter()
-    while n < 1 or (time.perf_counter() - t0 < 15.0 and n < 8):
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < max_steps):
         step()
         n += 1
+    return batch * n / (time.perf_counter() - t0), n, step
+
+
+def cpu_baseline(args, filters):
+    """The reference's CPU path (torch CPU fp32, all host cores) restated by oracle/unet_ref.py + oracle/postproc_ref.c,
+    timed on the GPU box's host next to the GPU numbers.  Baseline only — never what is shipped or
+    measured as `value`.  Headline entry = this run's workload at batch 2; `configs` holds the other BASELINE shapes:
+    configs[0] in full (2-level [8,16] net, 32 train + 8 val crops, batch 2, one epoch), the configs[2] shape (320x320),
+    and configs[4] (one 2048x2048 frame through the CPU network and the single-threaded C post-processing)."""
+    import numpy as np
+    from oracle import postproc_ref, unet_ref
+    from microbeseg_amd.utils import synth
+    from microbeseg_amd.utils.unets import build_unet
+    cores = min(host_cores(), 64)
+    torch.set_num_threads(cores)
+    rate, n, _ = _cpu_train_steps(args.arch, args.act, args.norm, filters, args.size, 2, 15.0, 8, cores)
+    out = {"value": round(rate, 4), "unit": "crops/s", "cores": cores, "kind": "port",
+           "sample": f"{n} training steps of batch 2 ({args.size}x{args.size}) through oracle/unet_ref.py "
+                     f"(torch CPU fp32, {cores} threads), same net/loss/Adam-amsgrad", "configs": {}}
+    if args.arch != "DU" or tuple(filters) != (64, 1024):
+        return out
+    # configs[0] in full: one epoch = 16 training + 4 validation steps of batch 2 on 256x256 crops, [8,16] DU-Net
+    _, _, step0 = _cpu_train_steps("DU", args.act, args.norm, (8, 16), 256, 2, 0.0, 1, cores)
+    t0 = time.perf_counter()
+    for _ in range(16):
+        step0(True)
+    for _ in range(4):
+        step0(False)
     dt = time.perf_counter() - t0
-    return {"value": round(b * n / dt, 4), "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{n} training steps of batch {b} ({args.size}x{args.size}) through oracle/unet_ref.py "
-                      f"(torch CPU fp32, {cores} threads), same net/loss/Adam-amsgrad"}
+    out["configs"]["configs[0]"] = {"value": round(40 / dt, 2), "unit": "crops/s", "epoch_s": round(dt, 3),
+                                    "sample": "full: DU-Net [8,16], 32 train + 8 val 256x256 crops, batch 2, 1 epoch"}
+    rate3, n3, _ = _cpu_train_steps("DU", args.act, args.norm, (64, 1024), 320, 2, 8.0, 3, cores)
+    out["configs"]["configs[2] shape"] = {"value": round(rate3, 4), "unit": "crops/s",
+                                          "sample": f"{n3} fp32 training steps of batch 2 at 320x320 (the CPU path has "
+                                                    f"no bf16 mode)"}
+    # configs[4]: 2048x2048 frame, network forward (eval) on the host cores + the C oracle of the post-processing
+    torch.manual_seed(0)
+    holder = build_unet("DU", args.act, "conv", args.norm, "cpu", 1, ch_out=1, filters=(64, 1024))
+    sd = {k: v.detach() for k, v in holder.state_dict().items()}
+    S = args.infer_size
+    frame = torch.rand(1, 1, S, S) * 2 - 1
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        unet_ref.unet_forward(sd, frame, "DU", args.act, args.norm, (64, 1024), training=False)
+    t_net = time.perf_counter() - t0
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2), rmin=5.0, rmax=13.0)
+    t0 = time.perf_counter()
+    postproc_ref.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
+    t_pp = time.perf_counter() - t0
+    out["configs"]["configs[4]"] = {"value": round(S * S / (t_net + t_pp) / 1e6, 3), "unit": "Mpx/s",
+                                    "net_s": round(t_net, 2), "postproc_s": round(t_pp, 3),
+                                    "sample": f"1 frame {S}x{S}: DU-Net [64,1024] forward on {cores} threads + C oracle of "
+                                              f"the post-processing on 1 thread (scipy / scikit-image are single-threaded)"}
+    return out
 
 
 def inference_metric(args, net, dev):
