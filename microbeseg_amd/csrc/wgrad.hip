@@ -435,8 +435,10 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
   const int ntiles_n = (Nch + 63) / 64;
   const int ntiles = ((Mch + 63) / 64) * ntiles_n;
   const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
-  const int tile = lid % ntiles;
-  const int ky = (lid / ntiles) % 3;
+  // kernel row fastest: the three row-workgroups of a (channel tile, split) have neighbouring logical ids, i.e. run on ONE
+  // XCD at about the same time, and fetch the same P slab and two thirds of each other's Q rows out of that XCD's L2
+  const int ky = lid % 3;
+  const int tile = (lid / 3) % ntiles;
   const int split = lid / (ntiles * 3);
   const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
 

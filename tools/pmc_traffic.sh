@@ -10,12 +10,16 @@ out=$PWD/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference "$@" > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block "$@" > $out/$c.log 2>&1
 done
 cd $out
-python3 - "$tag" <<'PY'
+python3 - "$tag" "$GRAFT_REPO_ROOT" "$@" <<'PY'
 import csv, glob, collections, json, sys
-tag = sys.argv[1]
+tag, root = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+sys.argv = ["bench.py"] + sys.argv[3:]
+import bench
+config = bench.workload_key(bench.parse())       # bench.py picks the profile of ITS workload by this record
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -35,7 +39,9 @@ for k, v in agg.items():
     write = v["WRITE_SIZE"] * 1024 / max(len(cnt[(k, "WRITE_SIZE")]), 1)
     res[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
               "hbm_bytes_per_launch": fetch + write}
+res["__config__"] = config
 json.dump(res, open(f"../traffic_{tag}.json", "w"), indent=1, sort_keys=True)
+del res["__config__"]
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
     print(f"{k[:60]:60s} n={v['launches']:4d} fetch {v['fetch_bytes_per_launch']/1e6:9.1f} MB write {v['write_bytes_per_launch']/1e6:9.1f} MB")
 PY
