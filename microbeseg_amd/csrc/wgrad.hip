@@ -630,6 +630,220 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const MsegWgrad p, int 
 }
 
 // =====================================================================================================================
+// All nine taps in one workgroup (3x3 stride-1 layers whose rows are a multiple of 4; the default network: every layer).
+// wgrad_halo_kernel gives each kernel ROW its own workgroup, so P and two thirds of Q are fetched three times (measured:
+// 1.2 GB of HBM traffic per launch against 0.56 GB of operands).  Here a workgroup owns a 64 x 64 channel tile for ALL taps
+// (9 x 16 accumulator registers per lane, two workgroups per CU) and walks 32-pixel blocks of TH x TW = 4 x 8 (or 8 x 4)
+// pixels: per block ONE (TH + 2) x (TW + 2) = 60-pixel halo image of Q and the 32-pixel P slab are staged, and every tap
+// reads its MFMA B fragments from the halo at a constant row offset (ky * (TW + 2) + kx) — 144 MFMAs per wave and
+// barrier against 6 staged float4 per thread (the row kernel: 48 against 5), operands fetched once.
+template <int TWL, int QTR>
+__global__ __launch_bounds__(256, 2) void wgrad_halo9_kernel(const MsegWgrad p, int splits, int steps_per_split) {
+  constexpr int tw_log2 = TWL;
+  constexpr int PTR = 0;
+  constexpr int QROWS_MAX = 64;                       // (TH + 2) x (TW + 2) = 6 x 10 or 10 x 6 = 60 rows, staged in 4 passes
+  constexpr int STAGE = (WG_PIX + QROWS_MAX) * WH_LDS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Mch = p.P.C, Nch = p.Nch;
+  const int ntiles_n = (Nch + 63) / 64;
+  const int ntiles = ((Mch + 63) / 64) * ntiles_n;
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  // channel tiles of one split (= one pixel range) are neighbours: they run on one XCD and share its L2 for P and Q
+  const int tile = lid % ntiles;
+  const int split = lid / ntiles;
+  const int mt = tile / ntiles_n, nt = tile - mt * ntiles_n;
+
+  constexpr int TW = 1 << tw_log2, TH = WG_PIX >> tw_log2, QW = TW + 2;
+  constexpr int QROWS = (TH + 2) * QW;                 // ONE halo image serves all nine taps
+  const int bx = p.Wp >> tw_log2, by = (p.Hp + TH - 1) / TH;      // blocks per image row / column
+  const int steps_img = bx * by;
+  const int steps_total = p.NB * steps_img;
+  const int step_begin = split * steps_per_split;
+  int step_end = step_begin + steps_per_split;
+  if (step_end > steps_total) step_end = steps_total;
+  const int nsteps = step_end > step_begin ? step_end - step_begin : 0;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int spx = tid >> 4, sc4 = tid & 15;
+  const int mc = mt * 64 + sc4 * 4;
+  const int qc = nt * 64 + sc4 * 4;
+  const bool q1 = (p.nq > 1) && (nt * 64 >= p.Q[0].C);
+  const MsegSrc& qs = q1 ? p.Q[1] : p.Q[0];
+  const bool mvalid = mc < Mch, qvalid = qc < Nch;
+  const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
+  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
+  const unsigned OOB = 0x80000000u;
+  // buffer descriptors of ONE image, re-based whenever the walk enters the next image: 32-bit offsets only have to span
+  // an image (< 2 GiB, host-checked), so the batch size is unlimited
+  const int HWp = p.Hp * p.Wp;
+  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWp * qs.C * 4, 0x00020000);
+  int desc_n = 0;
+  float4 psc, psh, qsc, qsh;
+  {
+    const float* a = (PTR && p.P.scale) ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
+    const float* b = (PTR && p.P.scale) ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
+    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
+    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
+    psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
+    qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
+  }
+  const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+  const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+
+  // wave-uniform position of the NEXT block to load: image sn, first row spy, first column spx0
+  int sn = step_begin / steps_img;
+  const int srem0 = step_begin - sn * steps_img;
+  int spy = (srem0 / bx) * TH, spx0 = (srem0 - (srem0 / bx) * bx) * TW;
+  // per-thread constants.  P rows k = spx, spx + 16 (pixel (k / TW, k % TW) of the block); Q slab rows s = spx, spx + 16,
+  // spx + 32 (halo position (s / QW, s % QW), column qx = px0 - pad + s % QW)
+  int pr[2], pcol[2];
+  unsigned pv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = spx + 16 * i;
+    pr[i] = k >> tw_log2; pcol[i] = k & (TW - 1);
+    pv[i] = (unsigned)(pr[i] * p.Wp + pcol[i]) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
+  }
+  int qr[4], qj[4];
+  unsigned qv[4];
+  bool qlive[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int sidx = spx + 16 * i;
+    qlive[i] = sidx < QROWS;
+    qr[i] = sidx / QW; qj[i] = sidx - qr[i] * QW;
+    qv[i] = (unsigned)(qr[i] * p.Wq + qj[i]) * qC4 + qcl4;
+  }
+  // LDS float offset of the B fragment of pixel k = 2 kk + lh: slab row (k / TW) * QW + k % TW.  TW >= 2, so k and k - lh
+  // lie in the same block row: offset = compile-time part (kk) + lane part (lh, wn, li)
+  const int blane = lh * WH_LDS + wn * 32 + li;
+
+  float4 rp[2], rq[4];
+  float pm[2], qm[4];
+
+  // per-sample (Group/InstanceNorm) tables: a block lies in ONE image, so the tables of the step are wave-uniform in n
+  // and are re-read only when the image changes
+  const bool p_ps = PTR && p.P.scale && p.P.ss != 0;
+  const bool q_ps = QTR && qs.scale && qs.ss != 0;
+  int tab_n = -1;
+
+  auto issue = [&](int step) {
+    const bool live = step < nsteps;                                             // scalar
+    if ((p_ps || q_ps) && live && sn != tab_n) {
+      tab_n = sn;
+      if (p_ps) {
+        psc = *reinterpret_cast<const float4*>(p.P.scale + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+        psh = *reinterpret_cast<const float4*>(p.P.shift + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+      }
+      if (q_ps) {
+        qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+        qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+      }
+    }
+    if (live && sn != desc_n) {                                                  // scalar: next image
+      desc_n = sn;
+      rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr + (size_t)sn * HWp * Mch), 0, HWp * Mch * 4,
+                                              0x00020000);
+      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWp * qs.C), 0, HWp * qs.C * 4,
+                                              0x00020000);
+    }
+    const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;                  // scalar: first pixel of the block
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool pok = live & mvalid & (spy + pr[i] < p.Hp);                     // rows below the image: zeros
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv[i] : OOB, psoff, 0));
+      rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+      if (PTR) pm[i] = pok ? 1.f : 0.f;
+    }
+    const int qy0 = spy - p.pad, qx0 = spx0 - p.pad;                             // scalar: halo origin
+    const unsigned sb = (unsigned)(qy0 * p.Wq + qx0) * qC4;                      // scalar, wraps by design (halo rows < 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < 3 || qlive[i]) {
+        const int qy = qy0 + qr[i], qx = qx0 + qj[i];
+        const bool ok = live & qvalid & qlive[i] & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? sb + qv[i] : OOB, 0, 0));
+        rq[i] = make_float4(q[0], q[1], q[2], q[3]);
+        if (QTR) qm[i] = ok ? 1.f : 0.f;
+      }
+    }
+    // advance the scalar position by one block
+    spx0 += TW;
+    if (spx0 >= p.Wp) { spx0 = 0; spy += TH; if (spy >= p.Hp) { spy = 0; sn += 1; } }
+  };
+
+  auto xf = [&](float4 v, const float4& sc, const float4& sh, float m, int act, float lo, int tr) -> float4 {
+    if (tr == 0) return v;
+    if (tr == 2) v = act_fwd4(v, act);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+
+  auto commit = [&](float* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(stage + (spx + 16 * i) * WH_LDS + sc4 * 4) =
+          xf(rp[i], psc, psh, PTR ? pm[i] : 1.f, p.P.act, plo, PTR);
+    float* qst = stage + WG_PIX * WH_LDS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < 3 || qlive[i])
+        *reinterpret_cast<float4*>(qst + (spx + 16 * i) * WH_LDS + sc4 * 4) =
+            xf(rq[i], qsc, qsh, QTR ? qm[i] : 1.f, qs.act, qlo, QTR);
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    commit(lds);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    issue(step + 1);
+    const float* st = lds + buf * STAGE;
+    const float* qst = st + WG_PIX * WH_LDS + blane;
+    float a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) a[kk] = st[(2 * kk + lh) * WH_LDS + wm * 32 + li];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                      // tap (ky, kx) = row + ky, column + kx of the halo image
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float b = qst[(((((2 * kk) >> tw_log2) + t / 3) * QW + ((2 * kk) & (TW - 1))) + t % 3) * WH_LDS];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b, acc[t], 0, 0, 0);
+      }
+    }
+    commit(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const int n = nt * 64 + wn * 32 + li;
+  if (n < Nch) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < Mch) p.ws[(((size_t)split * 9 + t) * Mch + m) * Nch + n] = acc[t][r];
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
 // bf16 variant of the halo kernel (BASELINE configs[2]; MsegWgrad.precision == MSEG_PREC_BF16).
 // The contraction of a weight gradient runs over PIXELS, while the tensors are channel-contiguous (NHWC): the matrix cores
 // want every lane to hold 8 consecutive pixels of one channel.  gfx950's transposing LDS read (ds_read_b64_tr_b16) does
@@ -985,6 +1199,11 @@ static WgradSel wgrad_select(const MsegWgrad& p) {
   const bool fast = halo || (whole_fits && pix_ok && concat_ok &&
                              (!w.per_sample || ((long long)p.Hp * p.Wp) % WG_PIX == 0));
   w.kind = fast ? (halo ? 2 : 1) : 0;
+  if (halo) {
+    // all taps per workgroup on 4 x 8 / 8 x 4 pixel blocks, when at most 20 % of the block rows hang over the image bottom
+    const int tw9 = (p.Wp % 8) == 0 ? 3 : 2, TH9 = WG_PIX >> tw9;
+    if ((long long)p.Hp * 5 >= (long long)((p.Hp + TH9 - 1) / TH9) * TH9 * 4) { w.kind = 6; w.tw_log2 = tw9; }
+  }
   return w;
 }
 
@@ -994,16 +1213,16 @@ static int wgrad_plan(const MsegWgrad& p, int& splits, int& steps_per_split) {
   long long steps_total = (Ptot + WG_PIX - 1) / WG_PIX;
   const WgradSel sel = wgrad_select(p);
   if (sel.kind < 0) return MSEG_EINVAL;
-  if (sel.kind == 2) {
+  if (sel.kind == 2 || sel.kind == 6) {
     const int TH = WG_PIX >> sel.tw_log2;
-    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks (wgrad_halo_kernel)
+    steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks (wgrad_halo*_kernel)
   }
   if (sel.kind >= 3) {
     const int TH = (sel.kind == 3 ? 64 : 32) >> sel.tw_log2;
     steps_total = (long long)p.NB * ((p.Hp + TH - 1) / TH) * (p.Wp >> sel.tw_log2);   // pixel blocks, all taps per workgroup
   }
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
-  const int per_split_wgs = sel.kind >= 3 ? tiles : tiles * p.KH;
+  const int per_split_wgs = sel.kind >= 3 ? tiles : tiles * p.KH;      // kinds >= 3: all taps in one workgroup
   // 768 workgroups = one full round of 3 resident workgroups on each of the 256 CUs (bf16 kernel: 2 resident -> 512)
   const int round_wgs = sel.kind >= 3 ? 512 : 768;
   long long s = p.splits > 0 ? p.splits : (round_wgs + per_split_wgs - 1) / per_split_wgs;
@@ -1082,6 +1301,13 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
         if (tw_log2 == 3) MSEG_WB_Q(3); else MSEG_WB_Q(2);
 #undef MSEG_WB_Q
 #undef MSEG_WB
+        MSEG_LAUNCH_CHECK();
+      } else if (sel.kind == 6) {
+#define MSEG_W9(T_, Q_) hipLaunchKernelGGL((wgrad_halo9_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_W9_Q(T_) do { if (qtr == 0) MSEG_W9(T_, 0); else if (qtr == 1) MSEG_W9(T_, 1); else MSEG_W9(T_, 2); } while (0)
+        if (tw_log2 == 3) MSEG_W9_Q(3); else MSEG_W9_Q(2);
+#undef MSEG_W9_Q
+#undef MSEG_W9
         MSEG_LAUNCH_CHECK();
       } else if (sel.kind == 2) {
 #define MSEG_WH(T_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)

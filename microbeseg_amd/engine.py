@@ -173,6 +173,10 @@ def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
     fast = halo or (concat_ok and ((not per_sample) or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and
                     all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs))
     if fast and halo:
+        tw9 = 3 if Wp % 8 == 0 else 2                 # all nine taps per workgroup on 4 x 8 / 8 x 4 pixel blocks
+        th9 = 32 >> tw9
+        if Hp * 5 >= ((Hp + th9 - 1) // th9) * th9 * 4:
+            return "wgrad_halo9_kernel<%d, %d>" % (tw9, max(_tr_of(s) for s in Qs))
         twl = 5
         while Wp % (1 << twl):
             twl -= 1

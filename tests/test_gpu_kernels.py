@@ -166,6 +166,41 @@ def test_conv3x3_wgrad(eng, N, Cin, Cout, H, W, stride):
     assert rel_err(dW.cpu(), w.grad) < TOL
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act,per_sample,two_src", [
+    (2, 64, 64, 16, 32, "relu", False, False),        # 4 x 8 pixel blocks (row length a multiple of 8)
+    (3, 72, 40, 30, 24, "relu", False, False),        # channel tails, block rows hanging over the image bottom
+    (2, 64, 128, 16, 20, "relu", False, False),       # row length a multiple of 4 only: 8 x 4 blocks
+    (2, 128, 64, 24, 16, "mish", False, False),       # any-activation transform
+    (3, 64, 64, 16, 16, "relu", True, False),         # per-sample (Group / InstanceNorm) tables
+    (2, 128, 64, 16, 16, "relu", False, True),        # virtual concat: two Q sources
+    (5, 64, 64, 64, 64, "relu", False, False),        # many steps: several pixel-range splits
+])
+def test_conv3x3_wgrad_all_taps_kernel(eng, N, Cin, Cout, H, W, act, per_sample, two_src):
+    """wgrad_halo9_kernel: one workgroup holds the accumulators of all nine taps of a 64 x 64 channel tile and reads them
+    from ONE staged halo image per 32-pixel block; every variant against torch's weight gradient (1e-4)."""
+    g = torch.Generator().manual_seed(17 + Cin + W)
+    z = rnd(g, N, Cin, H, W)
+    shape = (N, Cin) if per_sample else (Cin,)
+    scale, shift = rnd(g, *shape) * 0.3 + 1, rnd(g, *shape) * 0.1
+    xin = _transform_cpu(z, act, scale, shift, per_sample)
+    w = (rnd(g, Cout, Cin, 3, 3) * 0.1).requires_grad_(True)
+    y = F.conv2d(xin, w, None, padding=1)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    if two_src:
+        c0 = Cin // 2
+        qs = [_mk_node(eng, z[:, :c0], act, scale[..., :c0], shift[..., :c0], per_sample).src(),
+              _mk_node(eng, z[:, c0:], act, scale[..., c0:], shift[..., c0:], per_sample).src()]
+    else:
+        qs = [_mk_node(eng, z, act, scale, shift, per_sample).src()]
+    dz = nhwc(gy).cuda()
+    P = eng.plain_src(dz, Cout)
+    assert eng._wgrad_kernel_name(P, qs, N, H, W, H, W, 3, 1).startswith("wgrad_halo9_kernel<%d" % (3 if W % 8 == 0 else 2))
+    dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    eng.wgrad(P, qs, dW, N, H, W, H, W, 3, 3, 1, 1, eng.Workspace(torch.device("cuda")))
+    assert rel_err(dW.cpu(), w.grad) < TOL
+
+
 def test_convT_wgrad(eng):
     g = torch.Generator().manual_seed(9)
     N, Cin, Cout, H, W = 2, 32, 24, 6, 10
