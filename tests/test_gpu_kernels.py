@@ -189,10 +189,11 @@ def test_conv3x3_wgrad_all_taps_kernel(eng, N, Cin, Cout, H, W, act, per_sample,
     y.backward(gy)
     if two_src:
         c0 = Cin // 2
-        qs = [_mk_node(eng, z[:, :c0], act, scale[..., :c0], shift[..., :c0], per_sample).src(),
-              _mk_node(eng, z[:, c0:], act, scale[..., c0:], shift[..., c0:], per_sample).src()]
+        nodes = [_mk_node(eng, z[:, :c0], act, scale[..., :c0], shift[..., :c0], per_sample),
+                 _mk_node(eng, z[:, c0:], act, scale[..., c0:], shift[..., c0:], per_sample)]
     else:
-        qs = [_mk_node(eng, z, act, scale, shift, per_sample).src()]
+        nodes = [_mk_node(eng, z, act, scale, shift, per_sample)]
+    qs = [n.src() for n in nodes]          # MsegSrc holds raw pointers: the nodes must outlive the launch
     dz = nhwc(gy).cuda()
     P = eng.plain_src(dz, Cout)
     assert eng._wgrad_kernel_name(P, qs, N, H, W, H, W, 3, 1).startswith("wgrad_halo9_kernel<%d" % (3 if W % 8 == 0 else 2))
