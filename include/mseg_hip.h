@@ -139,7 +139,7 @@ int mseg_pack_weight(const float* src, float* dst, int T, int R, int Rpad, int C
 /* Every repack of a network in one launch, after an optimizer step (replaces the per-layer repacks of the conv
  * weights the forward / data-gradient kernels consume: unets.py:112,137,192,244 hold them in torch's layout).
  * `jobs_dev`: njobs records in DEVICE memory, sorted by first_block; job j owns blocks [first_block[j],
- * first_block[j+1]) of 1024 destination elements each, total_blocks in all.  dst / dst16 (bf16 operand) may be NULL. */
+ * first_block[j] + mseg_pack_job_blocks(T, Rpad, Cpad)), total_blocks in all.  dst / dst16 (bf16 operand) may be NULL. */
 typedef struct MsegPackJob {
   const float* src;
   float* dst;
@@ -148,6 +148,7 @@ typedef struct MsegPackJob {
   uint32_t first_block;
   uint32_t reserved;
 } MsegPackJob;
+unsigned mseg_pack_job_blocks(int T, int Rpad, int Cpad);
 int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned total_blocks, void* stream);
 
 /* ---- normalisation (BatchNorm2d / GroupNorm(8) / InstanceNorm2d applied AFTER the activation) --------------

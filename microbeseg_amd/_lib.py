@@ -70,6 +70,7 @@ SIGNATURES = {
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mseg_pack_job_blocks": (C.c_uint, [_I, _I, _I]),
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -1866,10 +1866,15 @@ extern "C" int mseg_pack_weight(const float* src, float* dst, int T, int R, int 
 
 // ---- all weight repacks of a network in ONE launch (called by the optimizer after it has updated the weights) ----------
 // jobs[] lives in device memory (uploaded once: weights are views of the optimizer's flat arena and the packed operands are
-// persistent buffers, so the pointers never change); block b serves job j with first_block[j] <= b < first_block[j+1],
-// 1024 destination elements per block.  dst (fp32 operand) and dst16 (bf16 operand of the MSEG_PREC_BF16 kernels) are
-// both optional.
+// persistent buffers, so the pointers never change); block b serves job j with first_block[j] <= b < first_block[j+1].
+// A block owns a 32 x 32 (r, c) tile of ALL T taps.  In torch's layouts the taps are innermost (st = 1) and either c or r
+// comes next (stride T), so for a fixed outer index the tile's source is ONE contiguous run of 32 T floats: the block reads
+// 32 such runs coalesced into LDS and writes [t][r][32 consecutive c] rows of 128 B — an element-wise gather would fetch
+// every source line T times from HBM (measured: 3.1 GB for 0.37 GB of weights).  dst (fp32 operand) and dst16 (bf16
+// operand of the MSEG_PREC_BF16 kernels) are both optional.
+#define PACK_TILE 32
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const MsegPackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[PACK_TILE * (PACK_TILE * 9 + 1)];      // T <= 9 (3x3 convs, 2x2 transposed convs)
   int lo = 0, hi = njobs - 1;
   const unsigned b = blockIdx.x;
   while (lo < hi) {                                  // last job whose first_block <= b
@@ -1877,20 +1882,40 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const MsegPackJ
     if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
   }
   const MsegPackJob j = jobs[lo];
-  const size_t total = (size_t)j.T * j.Rpad * j.Cpad;
-  const size_t base = (size_t)(b - j.first_block) * 1024u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const size_t i = base + (size_t)k * 256u + threadIdx.x;
-    if (i >= total) break;
-    const int c = (int)(i % (unsigned)j.Cpad);
-    const size_t tr = i / (unsigned)j.Cpad;
-    const int r = (int)(tr % (unsigned)j.Rpad);
-    const int t = (int)(tr / (unsigned)j.Rpad);
-    const float v = (c < j.C && r < j.R) ? j.src[(size_t)t * j.st + (size_t)r * j.sr + (size_t)c * j.sc] : 0.f;
-    if (j.dst) j.dst[i] = v;
-    if (j.dst16) ((__bf16*)j.dst16)[i] = (__bf16)v;
+  const int T = j.T;
+  const int ctiles = (j.Cpad + PACK_TILE - 1) / PACK_TILE;
+  const int tb = (int)(b - j.first_block);
+  const int r0 = (tb / ctiles) * PACK_TILE, c0 = (tb % ctiles) * PACK_TILE;
+  const bool inner_c = j.sc <= j.sr;                 // which of c / r is contiguous (after the taps) in the source
+  const int run = PACK_TILE * T, pitch = run + 1;    // odd pitch: the transposed reads below are bank-conflict free
+  const int o0 = inner_c ? r0 : c0, i0 = inner_c ? c0 : r0;
+  const int on = inner_c ? j.R : j.C, in = inner_c ? j.C : j.R;
+  const long long so = inner_c ? j.sr : j.sc, si = inner_c ? j.sc : j.sr;
+  const bool contiguous = j.st == 1 && si == T;
+  for (int e = threadIdx.x; e < PACK_TILE * run; e += 256) {
+    const int o = e / run, k = e - o * run;          // outer index in the tile, position in its run (= i * T + t)
+    const int i = k / T, t = k - i * T;
+    float v = 0.f;
+    if (o0 + o < on && i0 + i < in)
+      v = contiguous ? j.src[(long long)(o0 + o) * so + (long long)i0 * T + k]
+                     : j.src[(long long)t * j.st + (long long)(o0 + o) * so + (long long)(i0 + i) * si];
+    tile[o * pitch + k] = v;
   }
+  __syncthreads();
+  const int c = threadIdx.x & 31;
+  for (int q = threadIdx.x >> 5; q < PACK_TILE * T; q += 8) {
+    const int r = q % PACK_TILE, t = q / PACK_TILE;
+    if (r0 + r >= j.Rpad || c0 + c >= j.Cpad) continue;
+    const float v = inner_c ? tile[r * pitch + c * T + t] : tile[c * pitch + r * T + t];
+    const size_t d = ((size_t)t * j.Rpad + r0 + r) * j.Cpad + c0 + c;
+    if (j.dst) j.dst[d] = v;
+    if (j.dst16) ((__bf16*)j.dst16)[d] = (__bf16)v;
+  }
+}
+
+extern "C" unsigned mseg_pack_job_blocks(int T, int Rpad, int Cpad) {
+  if (T <= 0 || T > 9 || Rpad <= 0 || Cpad <= 0) return 0;
+  return (unsigned)(((Rpad + PACK_TILE - 1) / PACK_TILE) * ((Cpad + PACK_TILE - 1) / PACK_TILE));
 }
 
 extern "C" int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned total_blocks, void* stream) {

@@ -340,7 +340,7 @@ def repack_all(params):
             j.dst16 = None if e._t16 is None else e._t16.data_ptr()
             j.T, j.R, j.Rpad, j.C, j.Cpad, j.st, j.sr, j.sc = T, R, rpad, Cc, kpad, st, sr, sc
             j.first_block = nblk
-            nblk += (T * rpad * kpad + 1023) // 1024
+            nblk += _lib.load().mseg_pack_job_blocks(T, rpad, kpad)
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
         tab = (raw.to(entries[0].t.device), len(entries), nblk)
         _pack_tables[key] = tab

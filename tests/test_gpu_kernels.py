@@ -619,3 +619,34 @@ def test_bf16_strided_wgrads(eng, N, Cin, Cout, H, W):
     dWT = torch.full((Cin, Cout, 2, 2), float("nan"), device="cuda")
     eng.wgrad(node.src(), [Q], dWT, N, H, W, 2 * H, 2 * W, 2, 2, 2, 0, ws, precision="bf16")
     assert rel_err(dWT.cpu(), refT) < 5e-4
+
+
+def test_repack_all_equals_single_packs(eng):
+    """engine.repack_all (ONE launch over every packed operand of a network, LDS-tiled transposition; called by FusedAdam
+    after the update) against the per-operand pack kernel: forward and data-gradient operands of 3x3 convolutions, both
+    operands of a 2x2 transposed convolution (merged taps), channel counts that are no multiples of 32, fp32 and bf16."""
+    g = torch.Generator().manual_seed(12)
+    convs = [torch.nn.Parameter(rnd(g, co, ci, 3, 3).cuda()) for co, ci in ((64, 64), (40, 72), (128, 1), (8, 16))]
+    ups = [torch.nn.Parameter(rnd(g, ci, co, 2, 2).cuda()) for ci, co in ((128, 64), (24, 40))]
+    entries = []
+    for p in convs:
+        co, ci = p.shape[:2]
+        entries += [eng.pack_weight(p, 9, co, ci, 1, ci * 9, 9, kind="fwd"), eng.pack_weight(p, 9, ci, co, 1, 9, ci * 9, kind="dgrad")]
+    for p in ups:
+        ci, co = p.shape[:2]
+        entries += [eng.pack_weight(p, 4, co, ci, 1, 4, co * 4, merge_taps=True, kind="fwd"),
+                    eng.pack_weight(p, 4, ci, co, 1, co * 4, 4, kind="dgrad")]
+    for e in entries[::2]:
+        e.bf16()                                       # half of them also carry a bf16 operand
+    with torch.no_grad():
+        for p in convs + ups:
+            p.mul_(-1.5).add_(0.25)                    # "optimizer step": bumps the version counters
+    assert all(e.stale() for e in entries)
+    assert eng.repack_all(convs + ups) == len(entries)
+    assert not any(e.stale() for e in entries)
+    for e in entries:
+        T, R, rpad, Cc, kpad, st, sr, sc = e.job
+        once = eng.pack_weight(e.param.detach(), T, R, Cc, st, sr, sc, merge_taps=e.merge)
+        assert torch.equal(e.t, once.t)
+        if e._t16 is not None:
+            assert torch.equal(e._t16, once.t.to(torch.bfloat16))
