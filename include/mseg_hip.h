@@ -43,14 +43,16 @@ extern "C" {
  * scale == NULL means "no affine" (identity), act == MSEG_ACT_NONE means no activation.
  * This is how conv -> activation -> norm (src/utils/unets.py:163-173: ConvBlock.forward) is executed without ever
  * materialising the normalised tensor: the producing conv stores z = conv(x)+b, the consumer applies act+norm. */
+#define MSEG_ST_F32 0
+#define MSEG_ST_BF16 1 /* tensor stored as bfloat16 in HBM (BASELINE configs[2]); all arithmetic stays fp32 */
 typedef struct MsegSrc {
-  const float* ptr;   /* [N][H][W][C] */
-  const float* scale; /* [N][C] (ss == C) or [C] (ss == 0), or NULL */
+  const float* ptr;   /* [N][H][W][C]; holds bfloat16 elements when dtype == MSEG_ST_BF16 */
+  const float* scale; /* [N][C] (ss == C) or [C] (ss == 0), or NULL; always fp32 */
   const float* shift;
   int32_t C;
   int32_t act;
   int32_t ss;
-  int32_t reserved;
+  int32_t dtype;      /* MSEG_ST_F32 / MSEG_ST_BF16 */
 } MsegSrc;
 
 /* ---- implicit-GEMM convolution family (fp32 MFMA v_mfma_f32_32x32x2_f32) ---------------------------------
@@ -85,7 +87,9 @@ typedef struct MsegIgemm {
   int32_t Ngemm, epi, split, ld0, ld1, acc0, acc1, Cq;
   int32_t precision; /* MSEG_PREC_F32, or MSEG_PREC_BF16: bf16 matrix-core inputs, fp32 accumulate (BASELINE configs[2]) —
                       * 3x3 stride-1 launches only (MSEG_EINVAL otherwise); `w` then points at the bf16 copy of the
-                      * packed weights (mseg_f32_to_bf16); sources, bias and destinations stay fp32 */
+                      * packed weights (mseg_f32_to_bf16); bias stays fp32 */
+  int32_t dst_dtype; /* MSEG_ST_F32 / MSEG_ST_BF16: element type of dst0 / dst1.  bf16 sources (MsegSrc.dtype) and bf16
+                      * destinations need precision == MSEG_PREC_BF16 (MSEG_EINVAL otherwise) */
   /* optional split-K scratch (small batches: fewer 3x3 stride-1 tiles than workgroup slots).  ws == NULL or too small: the
    * launch simply is not split.  Size: mseg_igemm_workspace_bytes(). */
   void* ws;
@@ -125,10 +129,11 @@ int mseg_wgrad(const MsegWgrad* p, void* stream);
  * gradient for ch_in == 1: HBM-bound VALU kernels (9..36 multiply-adds per output), not worth a 32-channel matrix-core
  * K-step.  x4: raw network input, NHWC with 4 channels (zero padded); w / dW: torch layout (Cout, Cin, 3, 3);
  * z, dz: [N][H][W][Cout].  Cout % 4 == 0, Cout <= 256, 256 % (Cout / 4) == 0 — otherwise MSEG_EINVAL (use mseg_igemm). */
+/* z_dtype / dz_dtype: MSEG_ST_F32 or MSEG_ST_BF16 — how z is stored / dz is read (the network input x4 is always fp32) */
 int mseg_first_conv_fwd(const float* x4, const float* w, const float* bias, int N, int H, int W, int Cin, int Cout,
-                        float* z, void* stream);
+                        void* z, int z_dtype, void* stream);
 size_t mseg_first_wgrad_workspace_bytes(int N, int H, int W, int Cout);
-int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, int W, int Cout, float* dW, void* ws,
+int mseg_first_wgrad(const float* x4, const void* dz, int dz_dtype, int N, int H, int W, int Cout, float* dW, void* ws,
                      void* stream);
 
 /* strided repack of a weight tensor into the zero-padded [T][Rpad][Cpad] GEMM operand:
@@ -159,21 +164,23 @@ int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned tot
  *   (unets.py:127-128; torch BatchNorm2d defaults eps 1e-5, momentum 0.1).
  * ws: fp64 scratch, mseg_norm_workspace_bytes(N, HW, C).                                                      */
 size_t mseg_norm_workspace_bytes(int N, int HW, int C);
-int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
+/* st: MSEG_ST_F32 / MSEG_ST_BF16 = storage of the activation tensors of the call (z, act_out; gy, dz, act_in below).  With
+ * bf16 storage a thread owns 8 channels (C % 8 == 0) and the statistics are those of the values as stored.           */
+int mseg_norm_stats(const void* z, int N, int HW, int C, int st, int act, int norm, const float* gamma,
                     const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
-                    float* running_mean, float* running_var, float momentum, float* act_out, void* ws, void* stream);
+                    float* running_mean, float* running_var, float momentum, void* act_out, void* ws, void* stream);
 /* act_out (nullable): also store a = act(z).  Used for the expensive activations (mish / elu / leakyrelu): consumers then
  * read `a` with MSEG_ACT_NONE instead of re-evaluating the activation for each of the 9 taps in their K-loops.
  * mseg_activation: a = act(z) alone (eval-mode BatchNorm has no statistics pass).                              */
-int mseg_activation(const float* z, int N, int HW, int C, int act, float* act_out, void* stream);
+int mseg_activation(const void* z, int N, int HW, int C, int st, int act, void* act_out, void* stream);
 /* eval-mode BatchNorm: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale */
 int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
 /* backward through y = norm(act(z)): given gy = dL/dy writes dz = dL/dz (may alias gy), dgamma, dbeta
  * (NULL for IN) and optionally dbias_prev[c] = sum_p dz (the producing conv's bias gradient).               */
-int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
-                  const float* mean, const float* rstd, float* dz, float* dgamma, float* dbeta, float* dbias,
-                  const float* act_in /* nullable: a = act(z) stored by the forward */, void* ws, void* stream);
+int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C, int st, int act, int norm, const float* gamma,
+                  const float* mean, const float* rstd, void* dz, float* dgamma, float* dbeta, float* dbias,
+                  const void* act_in /* nullable: a = act(z) stored by the forward */, void* ws, void* stream);
 
 /* MaxPool2d(2, 2) of a norm-on-load operand (pool_method = 'max': unets.py:306-307,363-364).  Forward writes the plain
  * pooled tensor [N][H/2][W/2][C]; backward routes gout to the first maximum of each window (torch's rule) and writes
@@ -188,8 +195,9 @@ int mseg_head_fwd(const MsegSrc* src, int N, int HW, const float* w, const float
                   void* stream);
 /* gy[N][HW][C] = sum_co gout[n][co][p] * W[co][c];  dW[Co][C], db[Co] (fp64 accumulation, deterministic) */
 size_t mseg_head_bwd_workspace_bytes(int N, int HW, int C, int Co);
-int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw, float* gy,
-                  float* dW, float* db, void* ws, void* stream);
+int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw, void* gy,
+                  int gy_dtype /* MSEG_ST_*: storage of the gradient written to gy */, float* dW, float* db, void* ws,
+                  void* stream);
 
 /* softmax over the 3 boundary classes of logits [3][Hp][Wp] -> probabilities [Hp-pad_y][Wp-pad_x][3] (HWC), top/left
  * padding cropped: F.softmax(dim=1) + slice + transpose in front of boundary_postprocessing (infer.py:371-374). */

@@ -15,6 +15,7 @@ NORM = {"bn": 0, "gn": 1, "in": 2}
 MODE_CONV, MODE_TCONV = 0, 1
 EPI_PLAIN, EPI_SCATTER2X2 = 0, 1
 MORDER_LINEAR, MORDER_PARITY = 0, 1
+ST_F32, ST_BF16 = 0, 1      # tensor storage in HBM (MsegSrc.dtype, MsegIgemm.dst_dtype, `st` arguments)
 
 
 class MsegLibraryError(RuntimeError):
@@ -23,7 +24,7 @@ class MsegLibraryError(RuntimeError):
 
 class MsegSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("C", C.c_int32), ("act", C.c_int32), ("ss", C.c_int32), ("reserved", C.c_int32)]
+                ("C", C.c_int32), ("act", C.c_int32), ("ss", C.c_int32), ("dtype", C.c_int32)]
 
 
 class MsegIgemm(C.Structure):
@@ -35,7 +36,7 @@ class MsegIgemm(C.Structure):
                 ("mode", C.c_int32), ("morder", C.c_int32),
                 ("Ngemm", C.c_int32), ("epi", C.c_int32), ("split", C.c_int32), ("ld0", C.c_int32),
                 ("ld1", C.c_int32), ("acc0", C.c_int32), ("acc1", C.c_int32), ("Cq", C.c_int32),
-                ("precision", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("precision", C.c_int32), ("dst_dtype", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class MsegWgrad(C.Structure):
@@ -64,24 +65,24 @@ SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
     "mseg_igemm_workspace_bytes": (_SZ, [C.POINTER(MsegIgemm)]),
     "mseg_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
-    "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mseg_pack_job_blocks": (C.c_uint, [_I, _I, _I]),
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
-    "mseg_activation": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mseg_activation": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "mseg_norm_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mseg_norm_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mseg_maxpool2x2_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P]),
     "mseg_maxpool2x2_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _I, _P, _P, _I, _P]),
     "mseg_head_fwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _P, _I, _P, _P]),
     "mseg_head_bwd_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "mseg_head_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "mseg_head_bwd": (_I, [C.POINTER(MsegSrc), _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
     "mseg_softmax3_hwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mseg_loss_workspace_bytes": (_SZ, [_SZ]),
     "mseg_regression_loss": (_I, [_P, _P, _SZ, _I, _P, _P, _P]),

@@ -69,6 +69,9 @@ __device__ __forceinline__ float4 act_fwd4(float4 v, int act) {
   return v;
 }
 
+// 4 consecutive channels at element offset `e` of an MsegSrc tensor (fp32 or bf16 storage)
+__device__ __forceinline__ float4 src_load4(const MsegSrc& s, size_t e);
+
 // norm-on-load of 4 consecutive channels c..c+3 of sample n from an MsegSrc
 __device__ __forceinline__ float4 src_transform4(float4 v, const MsegSrc& s, int n, int c) {
   v = act_fwd4(v, s.act);
@@ -79,6 +82,48 @@ __device__ __forceinline__ float4 src_transform4(float4 v, const MsegSrc& s, int
   }
   return v;
 }
+
+// ---- bf16 tensor storage (MSEG_ST_BF16: BASELINE configs[2], "bf16 forward / backward") -----------------------------------
+// Activations (pre-activation conv outputs z, materialised activations) and activation gradients may live in HBM as bf16;
+// every kernel computes in fp32: widening is a 16-bit shift, narrowing is round-to-nearest-even (v_cvt_pk_bf16_f32).
+typedef __bf16 mseg_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  mseg_bf16x2 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 v) {
+  return make_float4(bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y));
+}
+__device__ __forceinline__ uint2 f32x4_to_bf16(float4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+
+// 4 consecutive channels at element offset `e` of a tensor stored as fp32 (S16 = false) or bf16 (true)
+template <bool S16>
+__device__ __forceinline__ float4 ld_f4(const void* base, size_t e) {
+  if (S16) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + e));
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + e);
+}
+template <bool S16>
+__device__ __forceinline__ void st_f4(void* base, size_t e, float4 v) {
+  if (S16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + e) = f32x4_to_bf16(v);
+  else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + e) = v;
+}
+// run-time flavour for the HBM-bound kernels that are not worth two instantiations
+__device__ __forceinline__ float4 ld_f4_rt(const void* base, size_t e, int bf16) {
+  return bf16 ? ld_f4<true>(base, e) : ld_f4<false>(base, e);
+}
+__device__ __forceinline__ void st_f4_rt(void* base, size_t e, float4 v, int bf16) {
+  if (bf16) st_f4<true>(base, e, v); else st_f4<false>(base, e, v);
+}
+__device__ __forceinline__ float ld_f1_rt(const void* base, size_t e, int bf16) {
+  return bf16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(base)[e] << 16)
+              : reinterpret_cast<const float*>(base)[e];
+}
+
+__device__ __forceinline__ float4 src_load4(const MsegSrc& s, size_t e) { return ld_f4_rt(s.ptr, e, s.dtype); }
 
 // XCD-aware workgroup order (MI355X: 8 XCDs, each with a private L2; hardware deals consecutive workgroup ids
 // round-robin over the XCDs).  Maps the hardware id to a logical id such that each XCD works on one CONTIGUOUS range of

@@ -12,7 +12,7 @@
 template <int CI>   // input channels actually multiplied: 1 (reference nets) or 4 (the padded tensor)
 __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __restrict__ x4, const float* __restrict__ w,
                                                              const float* __restrict__ bias, int N, int H, int W,
-                                                             int Cin, int Cout, float* __restrict__ z) {
+                                                             int Cin, int Cout, void* __restrict__ z, int z_dtype) {
   // w: torch layout [Cout][Cin][3][3]; thread (pixel slot, channel quad)
   const int CQ = Cout >> 2;                  // channel quads per pixel
   const int ppb = 256 / CQ;                  // pixels per workgroup pass
@@ -54,14 +54,14 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
         }
       }
     }
-    *reinterpret_cast<float4*>(z + (size_t)pix * Cout + co) = acc;
+    st_f4_rt(z, (size_t)pix * Cout + co, acc, z_dtype);
   }
 }
 
 // dW[co][0][t] = sum_p dz[p][co] * x[p + tap t][0]   (Cin = 1).  Stage 1: every workgroup reduces a contiguous pixel range
 // into part[block][9][Cout]; stage 2 sums the blocks in fixed order (deterministic, fp64).
-__global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restrict__ x4, const float* __restrict__ dz,
-                                                          int N, int H, int W, int Cout, int pix_per_block,
+__global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restrict__ x4, const void* __restrict__ dz,
+                                                          int dz_dtype, int N, int H, int W, int Cout, int pix_per_block,
                                                           float* __restrict__ part) {
   __shared__ float red[9][256 * 4 / 4 * 4];   // [tap][pixel slot * Cout + channel]  (256 threads x 4 channels)
   const int CQ = Cout >> 2;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restric
       const int n = (int)(pix / ((long long)H * W));
       const int rem = (int)(pix - (long long)n * H * W);
       const int y = rem / W, x = rem - y * W;
-      const float4 g = *reinterpret_cast<const float4*>(dz + (size_t)pix * Cout + co);
+      const float4 g = ld_f4_rt(dz, (size_t)pix * Cout + co, dz_dtype);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int iy = y + ky - 1;
@@ -147,18 +147,19 @@ static bool first_shape_ok(int N, int H, int W, int Cin, int Cout) {
 }
 
 extern "C" int mseg_first_conv_fwd(const float* x4, const float* w, const float* bias, int N, int H, int W, int Cin,
-                                   int Cout, float* z, void* stream) {
+                                   int Cout, void* z, int z_dtype, void* stream) {
   if (!x4 || !w || !z || !first_shape_ok(N, H, W, Cin, Cout)) return MSEG_EINVAL;
+  if (z_dtype != MSEG_ST_F32 && z_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
   const long long P = (long long)N * H * W;
   const int ppb = 256 / (Cout >> 2);
   long long blocks = (P + ppb - 1) / ppb;
   if (blocks > 8192) blocks = 8192;
   if (Cin == 1)
     hipLaunchKernelGGL((first_conv_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x4, w, bias,
-                       N, H, W, Cin, Cout, z);
+                       N, H, W, Cin, Cout, z, z_dtype);
   else
     hipLaunchKernelGGL((first_conv_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x4, w, bias,
-                       N, H, W, Cin, Cout, z);
+                       N, H, W, Cin, Cout, z, z_dtype);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -170,14 +171,15 @@ extern "C" size_t mseg_first_wgrad_workspace_bytes(int N, int H, int W, int Cout
   return (size_t)blocks * 9 * Cout * sizeof(float);
 }
 
-extern "C" int mseg_first_wgrad(const float* x4, const float* dz, int N, int H, int W, int Cout, float* dW, void* ws,
-                                void* stream) {
+extern "C" int mseg_first_wgrad(const float* x4, const void* dz, int dz_dtype, int N, int H, int W, int Cout, float* dW,
+                                void* ws, void* stream) {
   if (!x4 || !dz || !dW || !ws || !first_shape_ok(N, H, W, 1, Cout)) return MSEG_EINVAL;
+  if (dz_dtype != MSEG_ST_F32 && dz_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
   int per;
   const int blocks = first_blocks((long long)N * H * W, Cout, &per);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x4, dz, N, H, W, Cout, per,
-                     (float*)ws);
+  hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x4, dz, dz_dtype, N, H, W, Cout,
+                     per, (float*)ws);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks,
                      Cout, dW);

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const MsegSrc s, int N, i
     float acc[HEAD_MAXCO] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
       for (int c4 = sub; c4 < C4; c4 += lpp) {
-        float4 v = *reinterpret_cast<const float4*>(s.ptr + (size_t)pix * s.C + c4 * 4);
+        float4 v = src_load4(s, (size_t)pix * s.C + c4 * 4);
         v = src_transform4(v, s, n, c4 * 4);
 #pragma unroll
         for (int co = 0; co < HEAD_MAXCO; ++co) {
@@ -89,8 +89,8 @@ extern "C" size_t mseg_head_bwd_workspace_bytes(int N, int HW, int C, int Co) {
 
 // thread owns 4 channels, walks the pixels of its chunk: gy = sum_co g[co]*W[co][c..c+3]; dW partial sums fp64
 __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom g, const float* __restrict__ w,
-                                                       const float* __restrict__ gout, float* __restrict__ gy,
-                                                       double* __restrict__ part) {
+                                                       const float* __restrict__ gout, void* __restrict__ gy,
+                                                       int gy_dtype, double* __restrict__ part) {
   __shared__ double red[256 * 4 * HEAD_MAXCO];
   __shared__ double redb[256];
   const int tid = threadIdx.x;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom
         wv[co] = co < g.Co ? *reinterpret_cast<const float4*>(w + (size_t)co * g.C + c) : make_float4(0, 0, 0, 0);
       for (int r = row_begin + r0; r < row_end; r += rpi) {
         const size_t off = ((size_t)n * g.HW + r) * g.C + c;
-        float4 yv = *reinterpret_cast<const float4*>(s.ptr + off);
+        float4 yv = src_load4(s, off);
         yv = src_transform4(yv, s, n, c);
         float4 o = make_float4(0, 0, 0, 0);
 #pragma unroll
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom
             if (c4 == 0) dbs[co] += gv;
           }
         }
-        *reinterpret_cast<float4*>(gy + off) = o;
+        st_f4_rt(gy, off, o, gy_dtype);
       }
     }
     for (int co = 0; co < g.Co; ++co) {
@@ -197,12 +197,14 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const double* __re
 }
 
 extern "C" int mseg_head_bwd(const MsegSrc* src, int N, int HW, const float* w, int Co, const float* gout_nchw,
-                             float* gy, float* dW, float* db, void* ws, void* stream) {
+                             void* gy, int gy_dtype, float* dW, float* db, void* ws, void* stream) {
   if (!src || !src->ptr || !w || !gout_nchw || !gy || !dW || !ws) return MSEG_EINVAL;
+  if (gy_dtype != MSEG_ST_F32 && gy_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
   if (N <= 0 || HW <= 0 || Co <= 0 || Co > HEAD_MAXCO || src->C <= 0 || (src->C & 3)) return MSEG_EINVAL;
   HeadGeom g = head_geom(N, HW, src->C, Co);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, *src, g, w, gout_nchw, gy, (double*)ws);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, *src, g, w, gout_nchw, gy, gy_dtype,
+                     (double*)ws);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((Co * (src->C + 1) + 31) / 32), dim3(256), 0, st,
                      (const double*)ws, g, dW, db);

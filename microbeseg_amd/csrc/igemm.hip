@@ -127,6 +127,7 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
   float* e_dst1 = pe->dst1;
   const int e_epi = pe->epi, e_split = pe->split, e_ld0 = pe->ld0, e_ld1 = pe->ld1, e_acc0 = pe->acc0,
             e_acc1 = pe->acc1, e_Cq = pe->Cq, e_morder = pe->morder, e_Ho = pe->Ho, e_Wo = pe->Wo, e_Ngemm = pe->Ngemm;
+  const bool e_d16 = pe->dst_dtype == MSEG_ST_BF16;   // destinations stored as bf16 (round to nearest even on store)
 #pragma unroll
   for (int b = 0; b < Cfg::NB; ++b) {
     const int n = n0 + wn * Cfg::TN + b * 32 + li;
@@ -189,11 +190,27 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
         // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16
         // memory round trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
         if (!nvalid || !tile_ok) continue;
-        float* const d = dst + base;
         const int rows_left = (tw_log2 >= 0) ? 32 : M - mb;      // halo tiles never straddle the end of M
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        if (e_d16) {
+          __bf16* const d = reinterpret_cast<__bf16*>(dst) + base;
+          if (accf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (row < rows_left) old[r] = (float)d[(unsigned)(row * step)];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < rows_left) d[(unsigned)(row * step)] = (__bf16)(acc[a][b][r] + bias + old[r]);
+          }
+          continue;
+        }
+        float* const d = dst + base;
         if (accf) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -231,8 +248,14 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
           off = (size_t)m * ld + noff;
         }
         float v = acc[a][b][r] + bias;
-        if (accf) v += dst[off];
-        dst[off] = v;
+        if (e_d16) {
+          __bf16* const d = reinterpret_cast<__bf16*>(dst);
+          if (accf) v += (float)d[off];
+          d[off] = (__bf16)v;
+        } else {
+          if (accf) v += dst[off];
+          dst[off] = v;
+        }
       }
     }
   }
@@ -941,13 +964,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define HB_STRIDE 40          // bf16 elements per LDS row
 
-template <int BN, int TR>
+// S16: the sources are bf16 tensors (MSEG_ST_BF16).  A thread then stages 8 channels per 16-byte load (half the loads and LDS
+// writes of the fp32-source form); a plain operand (TR = 0) goes to LDS as it arrives.
+template <int BN, int TR, bool S16>
 __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
                                                                  int chunks_per_split, int m_fastest) {
   constexpr int BM = 128;
   using Cfg = HaloCfg<BN>;
   constexpr int HMAX = 204;                          // (4 + 2) x (32 + 2), the largest halo (tw_log2 <= 5)
-  constexpr int HL = (HMAX * 8 + 511) / 512;         // float4 per thread per chunk (4)
+  constexpr int SQ = S16 ? 4 : 8;                    // staging threads per halo row (8 / 4 channels each)
+  constexpr int SROWS = 512 / SQ;                    // halo rows per staging pass
+  constexpr int HL = (HMAX + SROWS - 1) / SROWS;     // 16-byte loads per thread per chunk (4; 2 for bf16 sources)
   constexpr int ASTAGE = HMAX * HB_STRIDE;
   constexpr int BSTAGE = 3 * BN * HB_STRIDE;
   __shared__ __attribute__((aligned(16))) __bf16 lds[ASTAGE + 2 * BSTAGE];
@@ -957,7 +984,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int srow = tid >> 3, scol = tid & 7;         // halo staging: 64 rows x 8 channel quads per pass
+  const int srow = tid / SQ, scol = tid % SQ;        // halo staging: SROWS rows x SQ channel groups per pass
   const int brow = tid >> 2, bcol = tid & 3;         // weight staging: 128 rows x 4 groups of 8 channels
   const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
   const int HROWS = (TH + 2) * HW2;
@@ -991,7 +1018,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   unsigned hvalid = 0u;
 #pragma unroll
   for (int j = 0; j < HL; ++j) {
-    const int hrow = srow + 64 * j;
+    const int hrow = srow + SROWS * j;
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
@@ -1017,37 +1044,39 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
   const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
-  const float* const base0 = p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C;
-  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
-                                                                        band_rows * W * p.src[0].C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
-                                                                        band_rows * W * C1 * 4, 0x00020000);
+  constexpr int ESZ = S16 ? 2 : 4;                   // bytes per source element
+  const char* const base0 = (const char*)p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C * ESZ;
+  const char* const base1 = (const char*)(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1 * ESZ;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0), 0,
+                                                                        band_rows * W * p.src[0].C * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base1), 0,
+                                                                        band_rows * W * C1 * ESZ, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 2, 0x00020000);
   const bool bact = brow < BN;
   const unsigned wvoff = bact ? ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u : OOB;
 
-  float4 rh[HL], rsc, rsh;
+  f32x4 rh[HL];                                      // 16 raw bytes: 4 fp32 or 8 bf16 source channels
+  float4 rsc, rsh, rsc2, rsh2;                       // norm-on-load tables of this thread's 4 (8) channels
   f32x4 rb[3];
   unsigned hlive = 0u;
   int ract = 0;
   bool cur_s1 = false;
 
   auto issue_halo = [&](int chunk) {
-    const int c = chunk * KC + scol * 4;
+    constexpr int CPT = S16 ? 8 : 4;                 // channels per staging thread
+    const int c = chunk * KC + scol * CPT;
     cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
     const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
-    const unsigned sC4 = (unsigned)s.C * 4u;
-    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u + scol * 16u;
+    const unsigned sCB = (unsigned)s.C * (unsigned)ESZ;                            // bytes per pixel
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * (unsigned)ESZ + scol * 16u;
     hlive = (c < p.Cin) ? hvalid : 0u;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       const bool ok = (hlive >> j) & 1u;
-      const unsigned vo = ok ? (unsigned)hpix[j] * sC4 + soff : OOB;
-      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
-                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
-      rh[j] = make_float4(v[0], v[1], v[2], v[3]);
+      const unsigned vo = ok ? (unsigned)hpix[j] * sCB + soff : OOB;
+      rh[j] = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
     }
     if (TR != 0) {
       ract = s.act;
@@ -1058,26 +1087,45 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
       const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
       rsc = *reinterpret_cast<const float4*>(scp + o);
       rsh = *reinterpret_cast<const float4*>(shp + o);
+      if (S16) {                                     // g_ident_* hold 4 entries: the identity needs no second quad
+        rsc2 = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc;
+        rsh2 = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh;
+      }
     }
+  };
+
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo, float m) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
   };
 
   auto commit_halo = [&](__bf16* As) {
     const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
-      const int hrow = srow + 64 * j;
+      const int hrow = srow + SROWS * j;
       if (hrow < HMAX) {
-        float4 v = rh[j];
-        if (TR != 0) {
-          if (TR == 2) v = act_fwd4(v, ract);
-          else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
-          const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
-          v.x = (v.x * rsc.x + rsh.x) * m; v.y = (v.y * rsc.y + rsh.y) * m;
-          v.z = (v.z * rsc.z + rsh.z) * m; v.w = (v.w * rsc.w + rsh.w) * m;
+        const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+        if (S16) {
+          const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
+          if (TR == 0) {                             // plain bf16 operand: already in LDS format
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else {
+            const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
+            const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
+            const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = make_uint4(pa.x, pa.y, pb.x, pb.y);
+          }
+        } else {
+          float4 v = make_float4(rh[j][0], rh[j][1], rh[j][2], rh[j][3]);
+          if (TR != 0) v = xform4(v, rsc, rsh, lo, m);
+          bf16x4 h;
+          h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+          *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
         }
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
       }
     }
   };
@@ -1159,13 +1207,15 @@ struct HaloCfg4 {
   static constexpr int MB = 2, NB = 2;
 };
 
-template <int TR>
+template <int TR, bool S16>
 __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIgemm p, int tw_log2, int ksplit,
                                                                    int chunks_per_split, int m_fastest) {
   constexpr int BM = 128, BN = 128;
   using Cfg = HaloCfg4;
   constexpr int HMAX = 204;
-  constexpr int HL = (HMAX * 8 + 255) / 256;         // float4 per thread per chunk (7)
+  constexpr int SQ = S16 ? 4 : 8;                    // staging threads per halo row (8 / 4 channels each)
+  constexpr int SROWS = 256 / SQ;                    // halo rows per staging pass
+  constexpr int HL = (HMAX + SROWS - 1) / SROWS;     // 16-byte loads per thread per chunk (7; 4 for bf16 sources)
   constexpr int BP = BN / 64;                        // weight rows per thread and tap (2)
   constexpr int ASTAGE = HMAX * HB_STRIDE;
   constexpr int BSTAGE = 3 * BN * HB_STRIDE;
@@ -1176,7 +1226,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int srow = tid >> 3, scol = tid & 7;         // halo staging: 32 rows x 8 channel quads per pass
+  const int srow = tid / SQ, scol = tid % SQ;        // halo staging: SROWS rows x SQ channel groups per pass
   const int brow = tid >> 2, bcol = tid & 3;         // weight staging: 64 rows x 4 groups of 8 channels per pass
   const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
   const int HROWS = (TH + 2) * HW2;
@@ -1206,7 +1256,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   unsigned hvalid = 0u;
 #pragma unroll
   for (int j = 0; j < HL; ++j) {
-    const int hrow = srow + 32 * j;
+    const int hrow = srow + SROWS * j;
     const int hy = hrow / HW2, hx = hrow - hy * HW2;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
@@ -1232,37 +1282,39 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   const int C0 = p.src[0].C;
   const unsigned OOB = 0x80000000u;
   const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
-  const float* const base0 = p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C;
-  const float* const base1 = (p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base0), 0,
-                                                                        band_rows * W * p.src[0].C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base1), 0,
-                                                                        band_rows * W * C1 * 4, 0x00020000);
+  constexpr int ESZ = S16 ? 2 : 4;                   // bytes per source element
+  const char* const base0 = (const char*)p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C * ESZ;
+  const char* const base1 = (const char*)(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1 * ESZ;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0), 0,
+                                                                        band_rows * W * p.src[0].C * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base1), 0,
+                                                                        band_rows * W * C1 * ESZ, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         9 * p.Npad * p.Kpad * 2, 0x00020000);
   const unsigned wvoff = ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u;
   const unsigned wvstep = 64u * (unsigned)p.Kpad * 2u;                              // scalar: 64 weight rows further
 
-  float4 rh[HL], rsc, rsh;
+  f32x4 rh[HL];                                      // 16 raw bytes: 4 fp32 or 8 bf16 source channels
+  float4 rsc, rsh, rsc2, rsh2;
   f32x4 rbA[3][BP], rbB[3][BP];
   unsigned hlive = 0u;
   int ract = 0;
   bool cur_s1 = false;
 
   auto issue_halo = [&](int chunk) {
-    const int c = chunk * KC + scol * 4;
+    constexpr int CPT = S16 ? 8 : 4;                 // channels per staging thread
+    const int c = chunk * KC + scol * CPT;
     cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
     const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
-    const unsigned sC4 = (unsigned)s.C * 4u;
-    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * 4u + scol * 16u;
+    const unsigned sCB = (unsigned)s.C * (unsigned)ESZ;                            // bytes per pixel
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * (unsigned)ESZ + scol * 16u;
     hlive = (c < p.Cin) ? hvalid : 0u;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
       const bool ok = (hlive >> j) & 1u;
-      const unsigned vo = ok ? (unsigned)hpix[j] * sC4 + soff : OOB;
-      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
-                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
-      rh[j] = make_float4(v[0], v[1], v[2], v[3]);
+      const unsigned vo = ok ? (unsigned)hpix[j] * sCB + soff : OOB;
+      rh[j] = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
     }
     if (TR != 0) {
       ract = s.act;
@@ -1273,26 +1325,45 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
       const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
       rsc = *reinterpret_cast<const float4*>(scp + o);
       rsh = *reinterpret_cast<const float4*>(shp + o);
+      if (S16) {                                     // g_ident_* hold 4 entries: the identity needs no second quad
+        rsc2 = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc;
+        rsh2 = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh;
+      }
     }
+  };
+
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo, float m) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
   };
 
   auto commit_halo = [&](__bf16* As) {
     const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 #pragma unroll
     for (int j = 0; j < HL; ++j) {
-      const int hrow = srow + 32 * j;
+      const int hrow = srow + SROWS * j;
       if (hrow < HMAX) {
-        float4 v = rh[j];
-        if (TR != 0) {
-          if (TR == 2) v = act_fwd4(v, ract);
-          else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
-          const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
-          v.x = (v.x * rsc.x + rsh.x) * m; v.y = (v.y * rsc.y + rsh.y) * m;
-          v.z = (v.z * rsc.z + rsh.z) * m; v.w = (v.w * rsc.w + rsh.w) * m;
+        const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+        if (S16) {
+          const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
+          if (TR == 0) {                             // plain bf16 operand: already in LDS format
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else {
+            const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
+            const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
+            const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = make_uint4(pa.x, pa.y, pb.x, pb.y);
+          }
+        } else {
+          float4 v = make_float4(rh[j][0], rh[j][1], rh[j][2], rh[j][3]);
+          if (TR != 0) v = xform4(v, rsc, rsh, lo, m);
+          bf16x4 h;
+          h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+          *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
         }
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
       }
     }
   };
@@ -1389,7 +1460,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
 // igemm_fast_kernel with bf16 matrix-core inputs: same per-row offsets / tap masks / live-tap list and epilogue; the staged
 // source pixels are rounded to bf16 after the norm-on-load transform, the weights arrive as bf16, LDS rows are 32 bf16 +
 // pad (80 B), one K-step (one tap x 32 channels) is two v_mfma_f32_32x32x16_bf16 per 32 x 32 block.
-template <int BM, int BN, int TR, bool PER_SAMPLE>
+// S16: bf16 source tensors; a staging thread then owns 8 channels of a row (one 16-byte load), half as many passes.
+template <int BM, int BN, int TR, bool PER_SAMPLE, bool S16>
 __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p) {
   using Cfg = IgemmCfg<BM, BN>;
   constexpr int STAGE = (BM + BN) * HB_STRIDE;
@@ -1407,17 +1479,21 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
   const int tile_n = lid - tile_m * ntiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int T = p.KH * p.KW;
-  const int srow = tid >> 3, scol = tid & 7;
+  constexpr int SQ = S16 ? 4 : 8;                      // staging threads per source row (8 / 4 channels each)
+  constexpr int RS = 256 / SQ;                         // rows per staging pass
+  constexpr int AR = BM / RS;                          // staging passes (4; 2 for bf16 sources)
+  constexpr int CPT = S16 ? 8 : 4, ESZ = S16 ? 2 : 4;
+  const int srow = tid / SQ, scol = tid % SQ;
   const int brow = tid >> 2, bcol = tid & 3;
 
   const TapGeom geom = make_geom(p);
   const long long tile_px = tile_base_pixel(p, geom, m0, M);
-  int pix0[Cfg::AROWS];
-  int rown[Cfg::AROWS];
-  unsigned vmask[Cfg::AROWS];
+  int pix0[AR];
+  int rown[AR];
+  unsigned vmask[AR];
 #pragma unroll
-  for (int i = 0; i < Cfg::AROWS; ++i) {
-    const RowInfo r = decode_row(p, m0 + srow + 32 * i, M);
+  for (int i = 0; i < AR; ++i) {
+    const RowInfo r = decode_row(p, m0 + srow + RS * i, M);
     const int iy0 = (r.oy * geom.sm - geom.dir * geom.pad) >> geom.sh, ix0 = (r.ox * geom.sm - geom.dir * geom.pad) >> geom.sh;
     pix0[i] = (int)(((long long)r.n * p.Hi + iy0) * p.Wi + ix0 - tile_px);   // relative to the tile's descriptor base
     rown[i] = r.n < 0 ? 0 : r.n;
@@ -1444,59 +1520,63 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
   // based at the tile's first source pixel; every load is masked by vmask (dead rows use OOB), so the record count only
   // has to exceed the tile's span (host-checked to stay below 2 GiB)
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.src[0].ptr + tile_px * p.src[0].C), 0, 0x7ffffff0, 0x00020000);
+      const_cast<char*>((const char*)p.src[0].ptr + tile_px * p.src[0].C * ESZ), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>((p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + tile_px * (p.nsrc > 1 ? p.src[1].C : p.src[0].C)), 0,
-      0x7ffffff0, 0x00020000);
+      const_cast<char*>((const char*)(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) +
+                        tile_px * (p.nsrc > 1 ? p.src[1].C : p.src[0].C) * ESZ), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
                                                                         T * p.Npad * p.Kpad * 2, 0x00020000);
   unsigned wvoff[BPASS];
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) wvoff[i] = ((unsigned)(n0 + brow + 64 * i) * (unsigned)p.Kpad + bcol * 8u) * 2u;
 
-  constexpr int NSC = (TR == 0) ? 1 : (PER_SAMPLE ? Cfg::AROWS : 1);
-  float4 ra[Cfg::AROWS], rsc[NSC], rsh[NSC];
+  constexpr int NSC = (TR == 0) ? 1 : (PER_SAMPLE ? AR : 1);
+  f32x4 ra[AR];                                        // 16 raw bytes: 4 fp32 or 8 bf16 source channels
+  float4 rsc[NSC], rsh[NSC], rsc2[NSC], rsh2[NSC];
   f32x4 rb[BPASS];
-  float rm[Cfg::AROWS];
-  unsigned rowoff[Cfg::AROWS];
+  float rm[AR];
+  unsigned rowoff[AR];
   int ract = 0;
   int cur_chunk = -1;
   bool cur_s1 = false;
 
   auto issue = [&](int chunk, int t, int ky, int kx) {
-    const int c = chunk * KC + scol * 4;
+    const int c = chunk * KC + scol * CPT;
     if (chunk != cur_chunk) {
       cur_chunk = chunk;
       cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
-      const unsigned sC4 = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * 4u;
-      const unsigned cl4 = (unsigned)(cur_s1 ? c - C0 : c) * 4u;
+      const unsigned sCB = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * (unsigned)ESZ;      // bytes per pixel
+      const unsigned cl = (unsigned)(cur_s1 ? c - C0 : c);
 #pragma unroll
-      for (int i = 0; i < Cfg::AROWS; ++i) rowoff[i] = (unsigned)pix0[i] * sC4 + cl4;
+      for (int i = 0; i < AR; ++i) rowoff[i] = (unsigned)pix0[i] * sCB + cl * (unsigned)ESZ;
       if (TR != 0) {
         const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
         ract = s.act;
         const bool has_aff = s.scale != nullptr;
         const float* scp = has_aff ? s.scale : g_ident_scale;
         const float* shp = has_aff ? s.shift : g_ident_shift;
-        const unsigned cl = (c < p.Cin) ? (cl4 >> 2) : 0u;
+        const unsigned clv = (c < p.Cin) ? cl : 0u;
 #pragma unroll
         for (int i = 0; i < NSC; ++i) {
-          const size_t o = (size_t)(PER_SAMPLE ? rown[i] : 0) * (has_aff ? (unsigned)s.ss : 0u) + cl;
+          const size_t o = (size_t)(PER_SAMPLE ? rown[i] : 0) * (has_aff ? (unsigned)s.ss : 0u) + clv;
           rsc[i] = *reinterpret_cast<const float4*>(scp + o);
           rsh[i] = *reinterpret_cast<const float4*>(shp + o);
+          if (S16) {
+            rsc2[i] = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc[i];
+            rsh2[i] = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh[i];
+          }
         }
       }
     }
     const unsigned cbit = (c < p.Cin) ? (1u << t) : 0u;
-    const unsigned sC4 = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * 4u;
-    const unsigned delta = (unsigned)(geom.dir * ((ky >> geom.sh) * p.Wi + (kx >> geom.sh))) * sC4;
+    const unsigned sCB = (unsigned)(cur_s1 ? p.src[1].C : p.src[0].C) * (unsigned)ESZ;
+    const unsigned delta = (unsigned)(geom.dir * ((ky >> geom.sh) * p.Wi + (kx >> geom.sh))) * sCB;
 #pragma unroll
-    for (int i = 0; i < Cfg::AROWS; ++i) {
+    for (int i = 0; i < AR; ++i) {
       const bool ok = (vmask[i] & cbit) != 0u;
       const unsigned vo = ok ? rowoff[i] + delta : OOB;
-      const f32x4 v = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
-                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
-      ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      ra[i] = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
       if (TR != 0) rm[i] = ok ? 1.f : 0.f;
     }
     const unsigned wso = ((unsigned)t * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC) * 2u;
@@ -1505,25 +1585,36 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], wso, 0));
   };
 
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo, float m) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+
   auto commit = [&](__bf16* As, __bf16* Bs) {
     const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 #pragma unroll
-    for (int i = 0; i < Cfg::AROWS; ++i) {
-      float4 v = ra[i];
-      if (TR != 0) {
-        if (TR == 2) {
-          v = act_fwd4(v, ract);
+    for (int i = 0; i < AR; ++i) {
+      const int ti = PER_SAMPLE ? i : 0;
+      if (S16) {
+        const uint4 raw = __builtin_bit_cast(uint4, ra[i]);
+        if (TR == 0) {
+          *reinterpret_cast<uint4*>(As + (srow + RS * i) * HB_STRIDE + scol * 8) = raw;
         } else {
-          v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo);
+          const float4 u = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc[ti], rsh[ti], lo, rm[i]);
+          const float4 w = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2[ti], rsh2[ti], lo, rm[i]);
+          const uint2 pu = f32x4_to_bf16(u), pw = f32x4_to_bf16(w);
+          *reinterpret_cast<uint4*>(As + (srow + RS * i) * HB_STRIDE + scol * 8) = make_uint4(pu.x, pu.y, pw.x, pw.y);
         }
-        const float4 sc = rsc[PER_SAMPLE ? i : 0], sh = rsh[PER_SAMPLE ? i : 0];
-        const float m = rm[i];
-        v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
-        v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+      } else {
+        float4 v = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+        if (TR != 0) v = xform4(v, rsc[ti], rsh[ti], lo, rm[i]);
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(As + (srow + RS * i) * HB_STRIDE + scol * 4) = h;
       }
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(As + (srow + 32 * i) * HB_STRIDE + scol * 4) = h;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
@@ -1594,7 +1685,7 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
 // rest to dst1, each with its own leading dimension and accumulate flag.  One thread per 4 columns.
 __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, size_t M, int N,
                                            const float* __restrict__ bias, float* __restrict__ dst0, int ld0, int acc0,
-                                           float* __restrict__ dst1, int ld1, int acc1, int split) {
+                                           float* __restrict__ dst1, int ld1, int acc1, int split, int d16) {
   const int N4 = N >> 2;
   const size_t total = M * (size_t)N4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1607,17 +1698,20 @@ __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ ws, int ksp
     }
     if (bias) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
     const bool second = n >= split;                    // split % 4 == 0 (channel counts are multiples of 4)
-    float* d = second ? dst1 + m * ld1 + (n - split) : dst0 + m * ld0 + n;
+    void* base = second ? (void*)dst1 : (void*)dst0;
+    const size_t e = second ? m * ld1 + (n - split) : m * ld0 + n;
     if (second ? acc1 : acc0) {
-      const float4 o = *reinterpret_cast<const float4*>(d);
+      const float4 o = ld_f4_rt(base, e, d16);
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
-    *reinterpret_cast<float4*>(d) = s;
+    st_f4_rt(base, e, s, d16);
   }
 }
 
 static int check_src(const MsegSrc& s) {
   if (!s.ptr || s.C <= 0 || (s.C & 3)) return MSEG_EINVAL;
+  if (s.dtype != MSEG_ST_F32 && s.dtype != MSEG_ST_BF16) return MSEG_EINVAL;
+  if (s.dtype == MSEG_ST_BF16 && (s.C & 7)) return MSEG_EINVAL;      // 8 bf16 channels per 16-byte staging load
   if ((s.scale == nullptr) != (s.shift == nullptr)) return MSEG_EINVAL;
   if (s.scale && (s.ss & 3)) return MSEG_EINVAL;
   return MSEG_OK;
@@ -1685,6 +1779,11 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   if (p.morder == MSEG_MORDER_PARITY && ((p.Ho | p.Wo) & 1)) return MSEG_EINVAL;
   if (p.Ngemm <= 0) return MSEG_EINVAL;
   if (p.precision != MSEG_PREC_F32 && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
+  // bf16 tensor storage (sources and / or destinations) exists for the bf16 matrix-core kernels only
+  if (p.dst_dtype != MSEG_ST_F32 && p.dst_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
+  const bool s16 = p.src[0].dtype == MSEG_ST_BF16;
+  if (p.nsrc > 1 && p.src[1].dtype != p.src[0].dtype) return MSEG_EINVAL;
+  if ((s16 || p.dst_dtype == MSEG_ST_BF16) && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
   if (p.epi == MSEG_EPI_SCATTER2X2) {
     if (p.Cq <= 0 || p.Ngemm != 4 * p.Cq || p.morder != MSEG_MORDER_LINEAR) return MSEG_EINVAL;
   } else if (p.epi == MSEG_EPI_PLAIN) {
@@ -1748,15 +1847,22 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     if (ks > 1) {
       q.dst0 = (float*)p.ws; q.dst1 = nullptr; q.ld0 = p.Ngemm; q.ld1 = 0; q.split = p.Ngemm; q.acc0 = 0; q.acc1 = 0;
       q.bias = nullptr;
+      q.dst_dtype = MSEG_ST_F32;                       // partial sums stay fp32; the reduction rounds once
     }
     const dim3 hgrid((unsigned)(htiles * ks));
 #define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
     // weight tensor beyond ~2 MB (bf16) and several N tiles: pixel tiles fastest (see the kernel)
     const int m_fastest = ((long long)9 * p.Kpad * p.Ngemm * 2 > (2ll << 20)) && (p.Ngemm > BNv) ? 1 : 0;
-#define MSEG_HALO16(BN_, TR_) \
-  hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest)
-#define MSEG_HALO16W4(TR_) \
-  hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest)
+#define MSEG_HALO16(BN_, TR_)                                                                                          \
+  do {                                                                                                                 \
+    if (s16) hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_, true>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest); \
+    else hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_, false>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest);    \
+  } while (0)
+#define MSEG_HALO16W4(TR_)                                                                                             \
+  do {                                                                                                                 \
+    if (s16) hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, true>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);    \
+    else hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, false>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);       \
+  } while (0)
     if (p.precision == MSEG_PREC_BF16) {
       if (wide) { if (tr == 0) MSEG_HALO16W4(0); else if (tr == 1) MSEG_HALO16W4(1); else MSEG_HALO16W4(2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }
@@ -1772,7 +1878,7 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       if (blocks > 16384) blocks = 16384;
       hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p.ws, ks,
                          (size_t)M, p.Ngemm, p.bias, p.dst0, p.ld0, p.acc0, p.dst1, p.ld1, p.acc1,
-                         p.split < p.Ngemm ? p.split : p.Ngemm);
+                         p.split < p.Ngemm ? p.split : p.Ngemm, p.dst_dtype == MSEG_ST_BF16 ? 1 : 0);
       MSEG_LAUNCH_CHECK();
     }
     return MSEG_OK;
@@ -1780,8 +1886,11 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   if (p.precision == MSEG_PREC_BF16) {                             // bf16 inputs: the halo and the gather kernel only
     if (!fast) return MSEG_EINVAL;
     const int tr = plain ? 0 : (generic ? 2 : 1);
-#define MSEG_FAST16_LAUNCH(BM_, BN_, TR_, PS_) \
-  hipLaunchKernelGGL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_>), grid, block, 0, st, p)
+#define MSEG_FAST16_LAUNCH(BM_, BN_, TR_, PS_)                                                          \
+  do {                                                                                                  \
+    if (s16) hipLaunchKernelGGL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p);   \
+    else hipLaunchKernelGGL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);      \
+  } while (0)
 #define MSEG_FAST16_TILE(BM_, BN_)                                                        \
   do {                                                                                    \
     if (tr == 0) MSEG_FAST16_LAUNCH(BM_, BN_, 0, false);                                  \

@@ -13,13 +13,13 @@ struct NormGeom {
   int N, HW, C, chunks, rows_per_chunk;
 };
 
-static NormGeom norm_geom(int N, int HW, int C) {
+static NormGeom norm_geom(int N, int HW, int C, int vec = 4) {
   NormGeom g;
   g.N = N; g.HW = HW; g.C = C;
   // one workgroup per (chunk of rows, sample); aim at >= 4096 workgroups (16 per CU) with at least 16 rows per row slot
-  // of a workgroup (256 threads = rpi rows x C/4 channel quads), so that deep levels (few pixels, many channels) still
+  // of a workgroup (256 threads = rpi rows x C/vec channel groups), so that deep levels (few pixels, many channels) still
   // fill the chip and level 0 keeps long streaming loops
-  const int C4 = C >> 2;
+  const int C4 = C / vec;
   const int CW = C4 < 256 ? (C4 > 0 ? C4 : 1) : 256;
   const int rpi = 256 / CW;
   const int min_rows = 16 * rpi;
@@ -32,12 +32,42 @@ static NormGeom norm_geom(int N, int HW, int C) {
   return g;
 }
 
+// threads own 4 channels of an fp32 tensor, 8 of a bf16 tensor (16-byte accesses either way; C % 8 == 0 required for bf16)
+static inline int norm_vec(int st) { return st == MSEG_ST_BF16 ? 8 : 4; }
+
 extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0) return 0;
-  NormGeom g = norm_geom(N, HW, C);
+  NormGeom g = norm_geom(N, HW, C);          // the fp32 geometry has the larger chunk count
   // fp64 partials [N][chunks][3][C] + per-(n,c) sums [3][N][C] + fp32 k-tables [3][N][C] (2*N*C doubles)
   return ((size_t)N * g.chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
 }
+
+// V consecutive channels (V = 4: fp32 storage, V = 8: bf16 storage) at element offset e
+template <bool S16>
+struct NormVec {
+  static constexpr int V = S16 ? 8 : 4;
+  float v[V];
+  __device__ __forceinline__ void load(const void* base, size_t e) {
+    if (S16) {
+      const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + e);
+      v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+      v[V - 4] = bf16_lo(r.z); v[V - 3] = bf16_hi(r.z); v[V - 2] = bf16_lo(r.w); v[V - 1] = bf16_hi(r.w);
+    } else {
+      const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + e);
+      v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+  }
+  __device__ __forceinline__ void store(void* base, size_t e) const {
+    if (S16) {
+      uint4 r;
+      r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+      r.z = pack_bf16x2(v[V - 4], v[V - 3]); r.w = pack_bf16x2(v[V - 2], v[V - 1]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + e) = r;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+};
 
 // MODE 0: forward  sums of (a, a*a)           from z        (+ optional store of a = act(z) into `aio`)
 // MODE 1: backward sums of (gy, gy*a)         from (gy, z)  (a read from `aio` when given)
@@ -45,16 +75,18 @@ extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
 // MODE 3: a = act(z) only (eval-mode BatchNorm with an expensive activation: materialise it once for the consumers)
 // `aio`: for expensive activations (Mish / ELU / LeakyReLU path) the activated tensor is materialised once so that the
 // conv / wgrad K-loops do not re-evaluate transcendentals for each of the 9 taps and every output tile.
-template <int MODE>
-__global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict__ z, const float* __restrict__ gy,
-                                                        float* __restrict__ dz, const float* __restrict__ k1,
+// S16: z, gy, dz and aio are bf16 tensors (the sums are taken over the values as stored, i.e. of the rounded dz).
+template <int MODE, bool S16>
+__global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__ z, const void* __restrict__ gy,
+                                                        void* __restrict__ dz, const float* __restrict__ k1,
                                                         const float* __restrict__ k2, const float* __restrict__ k3,
                                                         int kss, NormGeom g, int act, double* __restrict__ part,
-                                                        float* __restrict__ aio) {
-  __shared__ double red[256 * 8];
+                                                        void* __restrict__ aio) {
+  constexpr int V = S16 ? 8 : 4;
+  __shared__ double red[256 * 2 * V];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, n = blockIdx.y;
-  const int C4 = g.C >> 2;
+  const int C4 = g.C / V;
   const int CW = C4 < 256 ? C4 : 256;
   const int rpi = 256 / CW;
   const int cq = tid % CW, r0 = tid / CW;
@@ -67,79 +99,88 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const float* __restrict_
   for (int cbase = 0; cbase < C4; cbase += CW) {
     const int c4 = cbase + cq;
     const bool active = (c4 < C4) && (r0 < rpi);
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    double s0[V], s1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
     if (active) {
-      const int c = c4 * 4;
-      float4 a1 = make_float4(0, 0, 0, 0), a2 = a1, a3 = a1;
+      const int c = c4 * V;
+      float a1[V], a2[V], a3[V];
       if (MODE == 2) {
-        a1 = *reinterpret_cast<const float4*>(k1 + (size_t)n * kss + c);
-        a2 = *reinterpret_cast<const float4*>(k2 + (size_t)n * kss + c);
-        a3 = *reinterpret_cast<const float4*>(k3 + (size_t)n * kss + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          a1[j] = k1[(size_t)n * kss + c + j]; a2[j] = k2[(size_t)n * kss + c + j]; a3[j] = k3[(size_t)n * kss + c + j];
+        }
       }
       // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
       // one load pair per trip left the pass latency-bound at ~3 TB/s
       constexpr int U = 4;
       for (int r = row_begin + r0; r < row_end; r += rpi * U) {
-        float4 zv[U], gv[U], av[U];
+        NormVec<S16> zv[U], gv[U], av[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int ru = r + u * rpi;
           ok[u] = ru < row_end;
           const size_t off = ((size_t)n * g.HW + (ok[u] ? ru : r)) * g.C + c;
-          zv[u] = *reinterpret_cast<const float4*>(z + off);
-          if ((MODE == 1 || MODE == 2) && aio) av[u] = *reinterpret_cast<const float4*>(aio + off);
-          if (MODE == 1 || MODE == 2) gv[u] = *reinterpret_cast<const float4*>(gy + off);
+          zv[u].load(z, off);
+          if ((MODE == 1 || MODE == 2) && aio) av[u].load(aio, off);
+          if (MODE == 1 || MODE == 2) gv[u].load(gy, off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!ok[u]) continue;
           const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
-          float4 a4;
+          NormVec<S16> a4;
           if ((MODE == 1 || MODE == 2) && aio) a4 = av[u];
-          else a4 = act_fwd4(zv[u], act);
-          if ((MODE == 0 || MODE == 3) && aio) *reinterpret_cast<float4*>(aio + off) = a4;
+          else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) a4.v[j] = act_fwd(zv[u].v[j], act);
+          }
+          if ((MODE == 0 || MODE == 3) && aio) {
+            a4.store(aio, off);
+            if (S16) a4.load(aio, off);      // the consumers read the ROUNDED activation: the statistics describe that
+          }
           if (MODE == 3) continue;
           if (MODE == 0) {
-            s0[0] += a4.x; s0[1] += a4.y; s0[2] += a4.z; s0[3] += a4.w;
-            s1[0] += (double)a4.x * a4.x; s1[1] += (double)a4.y * a4.y;
-            s1[2] += (double)a4.z * a4.z; s1[3] += (double)a4.w * a4.w;
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] += a4.v[j]; s1[j] += (double)a4.v[j] * a4.v[j]; }
           } else if (MODE == 1) {
-            s0[0] += gv[u].x; s0[1] += gv[u].y; s0[2] += gv[u].z; s0[3] += gv[u].w;
-            s1[0] += (double)gv[u].x * a4.x; s1[1] += (double)gv[u].y * a4.y;
-            s1[2] += (double)gv[u].z * a4.z; s1[3] += (double)gv[u].w * a4.w;
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] += gv[u].v[j]; s1[j] += (double)gv[u].v[j] * a4.v[j]; }
           } else {
-            float4 d;
-            d.x = (a1.x * gv[u].x + a2.x * a4.x + a3.x) * act_bwd(zv[u].x, act);
-            d.y = (a1.y * gv[u].y + a2.y * a4.y + a3.y) * act_bwd(zv[u].y, act);
-            d.z = (a1.z * gv[u].z + a2.z * a4.z + a3.z) * act_bwd(zv[u].z, act);
-            d.w = (a1.w * gv[u].w + a2.w * a4.w + a3.w) * act_bwd(zv[u].w, act);
-            *reinterpret_cast<float4*>(dz + off) = d;
-            s0[0] += d.x; s0[1] += d.y; s0[2] += d.z; s0[3] += d.w;
+            NormVec<S16> d;
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+              d.v[j] = (a1[j] * gv[u].v[j] + a2[j] * a4.v[j] + a3[j]) * act_bwd(zv[u].v[j], act);
+            d.store(dz, off);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s0[j] += S16 ? (float)(__bf16)d.v[j] : d.v[j];     // sum of dz as stored
           }
         }
       }
     }
     if (MODE == 3) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[tid * 8 + j] = s0[j];
-      red[tid * 8 + 4 + j] = s1[j];
+    for (int j = 0; j < V; ++j) {
+      red[tid * 2 * V + j] = s0[j];
+      red[tid * 2 * V + V + j] = s1[j];
     }
     __syncthreads();
     if (r0 == 0 && c4 < C4) {
-      double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+      double t0[V], t1[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
       for (int k = 0; k < rpi; ++k) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          t0[j] += red[(k * CW + cq) * 8 + j];
-          t1[j] += red[(k * CW + cq) * 8 + 4 + j];
+        for (int j = 0; j < V; ++j) {
+          t0[j] += red[(k * CW + cq) * 2 * V + j];
+          t1[j] += red[(k * CW + cq) * 2 * V + V + j];
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pout[c4 * 4 + j] = t0[j];
-        if (NS == 2) pout[g.C + c4 * 4 + j] = t1[j];
+      for (int j = 0; j < V; ++j) {
+        pout[c4 * V + j] = t0[j];
+        if (NS == 2) pout[g.C + c4 * V + j] = t1[j];
       }
     }
     __syncthreads();
@@ -322,21 +363,28 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
   return (unsigned)(b > cap ? cap : b);
 }
 
-extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, int norm, const float* gamma,
+#define NORM_PASS(MODE_, ...)                                                                                        \
+  do {                                                                                                               \
+    if (st_ == MSEG_ST_BF16) hipLaunchKernelGGL((norm_pass_kernel<MODE_, true>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((norm_pass_kernel<MODE_, false>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__);     \
+  } while (0)
+
+extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int act, int norm, const float* gamma,
                                const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
-                               float* running_mean, float* running_var, float momentum, float* act_out, void* ws,
+                               float* running_mean, float* running_var, float momentum, void* act_out, void* ws,
                                void* stream) {
   if (!z || !scale || !shift || !mean || !rstd || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
+  if (st_ != MSEG_ST_F32 && st_ != MSEG_ST_BF16) return MSEG_EINVAL;
+  if (st_ == MSEG_ST_BF16 && (C & 7)) return MSEG_EINVAL;
   if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
   if (norm < 0 || norm > 2) return MSEG_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  NormGeom g = norm_geom(N, HW, C);
+  NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
   double* part = (double*)ws;
   double* nc = part + (size_t)N * g.chunks * 3 * C;
-  hipLaunchKernelGGL((norm_pass_kernel<0>), dim3(g.chunks, N), dim3(256), 0, st, z, (const float*)nullptr,
-                     (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
-                     part, act_out);
+  NORM_PASS(0, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
+            (const float*)nullptr, 0, g, act, part, act_out);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -348,12 +396,13 @@ extern "C" int mseg_norm_stats(const float* z, int N, int HW, int C, int act, in
   return MSEG_OK;
 }
 
-extern "C" int mseg_activation(const float* z, int N, int HW, int C, int act, float* act_out, void* stream) {
+extern "C" int mseg_activation(const void* z, int N, int HW, int C, int st_, int act, void* act_out, void* stream) {
   if (!z || !act_out || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
-  NormGeom g = norm_geom(N, HW, C);
-  hipLaunchKernelGGL((norm_pass_kernel<3>), dim3(g.chunks, N), dim3(256), 0, (hipStream_t)stream, z,
-                     (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, 0, g, act, (double*)nullptr, act_out);
+  if ((st_ != MSEG_ST_F32 && st_ != MSEG_ST_BF16) || (st_ == MSEG_ST_BF16 && (C & 7))) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
+  NORM_PASS(3, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
+            (const float*)nullptr, 0, g, act, (double*)nullptr, act_out);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -368,23 +417,23 @@ extern "C" int mseg_bn_eval_coeffs(const float* gamma, const float* beta, const 
   return MSEG_OK;
 }
 
-extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int C, int act, int norm,
-                             const float* gamma, const float* mean, const float* rstd, float* dz, float* dgamma,
-                             float* dbeta, float* dbias, const float* act_in, void* ws, void* stream) {
+extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C, int st_, int act, int norm,
+                             const float* gamma, const float* mean, const float* rstd, void* dz, float* dgamma,
+                             float* dbeta, float* dbias, const void* act_in, void* ws, void* stream) {
   if (!gy || !z || !mean || !rstd || !dz || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 3)) return MSEG_EINVAL;
+  if ((st_ != MSEG_ST_F32 && st_ != MSEG_ST_BF16) || (st_ == MSEG_ST_BF16 && (C & 7))) return MSEG_EINVAL;
   if (norm < 0 || norm > 2) return MSEG_EINVAL;
   if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  NormGeom g = norm_geom(N, HW, C);
+  NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
   double* part = (double*)ws;
   double* nc = part + (size_t)N * g.chunks * 3 * C;
   float* k1 = (float*)(nc + (size_t)3 * N * C);
   float* k2 = k1 + (size_t)N * C;
   float* k3 = k2 + (size_t)N * C;
   const int kss = (norm == MSEG_NORM_BN) ? 0 : C;
-  hipLaunchKernelGGL((norm_pass_kernel<1>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, (float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act, part,
-                     const_cast<float*>(act_in));
+  NORM_PASS(1, z, gy, (void*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
+            part, const_cast<void*>(act_in));
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -393,8 +442,8 @@ extern "C" int mseg_norm_bwd(const float* gy, const float* z, int N, int HW, int
                      st, (const double*)nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta);
   MSEG_LAUNCH_CHECK();
   double* part2 = part;
-  hipLaunchKernelGGL((norm_pass_kernel<2>), dim3(g.chunks, N), dim3(256), 0, st, z, gy, dz, (const float*)k1,
-                     (const float*)k2, (const float*)k3, kss, g, act, part2, const_cast<float*>(act_in));
+  NORM_PASS(2, z, gy, dz, (const float*)k1, (const float*)k2, (const float*)k3, kss, g, act, part2,
+            const_cast<void*>(act_in));
   MSEG_LAUNCH_CHECK();
   if (dbias) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,

@@ -873,12 +873,17 @@ __device__ __forceinline__ wbf16x8 wb_tr_read8(const __bf16* lo, const __bf16* h
 // transform PTR; Q = the gradient of its output).  The Q image of a block is (S TH + KT - S) x (S TW + KT - S) pixels, a tap
 // is still a row offset and consecutive block pixels are S image rows apart — every lane of a transposed read supplies
 // its own row address, so the stride costs nothing.  Blocks are 32 pixels for S = 2 (the Q image is four times the block).
-template <int TWL, int QTR, int S = 1, int KT = 3, int PTR = 0>
+// S16: P and Q are bf16 tensors (MSEG_ST_BF16): a staging thread owns 8 channels of a row (one 16-byte load), half the
+// passes; a plain operand goes to LDS as it arrives.
+template <int TWL, int QTR, int S = 1, int KT = 3, int PTR = 0, bool S16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad p, int splits, int steps_per_split) {
   constexpr int PIX = S == 1 ? WB_PIX : 32, NT = KT * KT;
   constexpr int TW = 1 << TWL, TH = PIX >> TWL, QW = S * TW + KT - S, QH = S * TH + KT - S;
   constexpr int QROWS = QH * QW;                       // S = 1: 100 (8 x 8 blocks) or 108 (16 x 4); S = 2: 153 or 128
-  constexpr int NP = PIX / 16, NQ = (QROWS + 15) / 16;
+  constexpr int SQN = S16 ? 8 : 16;                    // staging threads per pixel row (8 / 4 channels each)
+  constexpr int RP = 256 / SQN;                        // pixel rows per staging pass
+  constexpr int CPT = S16 ? 8 : 4, ESZ = S16 ? 2 : 4;
+  constexpr int NP = PIX / RP, NQ = (QROWS + RP - 1) / RP;
   constexpr int PEL = 2 * PIX * 32, QEL = 2 * QROWS * 32;
   constexpr int STAGE = PEL + QEL;
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
@@ -908,30 +913,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int spx = tid >> 4, sc4 = tid & 15;
-  const int mc = mt * 64 + sc4 * 4;
-  const int qc = nt * 64 + sc4 * 4;
+  const int spx = tid / SQN, sc4 = tid % SQN;
+  const int mc = mt * 64 + sc4 * CPT;
+  const int qc = nt * 64 + sc4 * CPT;
   const bool q1 = (p.nq > 1) && (nt * 64 >= p.Q[0].C);
   const MsegSrc& qs = q1 ? p.Q[1] : p.Q[0];
   const bool mvalid = mc < Mch, qvalid = qc < Nch;
-  const unsigned qC4 = (unsigned)qs.C * 4u, mC4 = (unsigned)Mch * 4u;
-  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * 4u;
+  const unsigned qC4 = (unsigned)qs.C * (unsigned)ESZ, mC4 = (unsigned)Mch * (unsigned)ESZ;     // bytes per pixel
+  const unsigned qcl4 = (unsigned)(q1 ? qc - p.Q[0].C : qc) * (unsigned)ESZ;                    // byte offset of the channels
+  const int qcl = q1 ? qc - p.Q[0].C : qc;
   const unsigned OOB = 0x80000000u;
   const int HWp = p.Hp * p.Wp, HWq = p.Hq * p.Wq;
-  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * 4, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWq * qs.C * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr), 0, HWp * Mch * ESZ, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr), 0, HWq * qs.C * ESZ, 0x00020000);
   int desc_n = 0;
-  float4 qsc, qsh, psc, psh;
+  float4 qsc, qsh, psc, psh, qsc2, qsh2, psc2, psh2;   // ...2: channels 4..7 of a bf16-source thread
   if (PTR) {
     const float* a = p.P.scale ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
     const float* b = p.P.scale ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
     psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
+    if (S16) {
+      psc2 = p.P.scale ? *reinterpret_cast<const float4*>(a + 4) : psc;
+      psh2 = p.P.scale ? *reinterpret_cast<const float4*>(b + 4) : psh;
+    }
   }
   const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
   {
-    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_scale;
-    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? (int)(qcl4 >> 2) : 0) : g_wg_ident_shift;
+    const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? qcl : 0) : g_wg_ident_scale;
+    const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? qcl : 0) : g_wg_ident_shift;
     qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
+    if (S16) {
+      qsc2 = (QTR && qs.scale) ? *reinterpret_cast<const float4*>(c + 4) : qsc;
+      qsh2 = (QTR && qs.scale) ? *reinterpret_cast<const float4*>(d + 4) : qsh;
+    }
   }
   const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 
@@ -944,24 +958,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   // the rows of a thread is wave-uniform.  Address constants are kept few on purpose: the 144 accumulators + 44 staging
   // registers leave no room, and a spilled constant is reloaded in every step.
   const int pr0 = spx >> TWL;
-  const unsigned pv0 = (unsigned)(pr0 * p.Wp + (spx & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * 4u;
-  const unsigned pvstep = (unsigned)((16 >> TWL) * p.Wp) * mC4;                  // scalar
+  const unsigned pv0 = (unsigned)(pr0 * p.Wp + (spx & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * (unsigned)ESZ;
+  const unsigned pvstep = (unsigned)((RP >> TWL) * p.Wp) * mC4;                  // scalar
   int qrj[NQ];                                         // halo row << 8 | halo column
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    const int sidx = spx + 16 * i;
+    const int sidx = spx + RP * i;
     const int r = sidx / QW, c = sidx - r * QW;
     qrj[i] = (r << 8) | c;
   }
   // LDS element offsets of this thread's staging writes: plane (sc4 >> 3), row, 4 channels at (sc4 & 7) * 4
-  const int wplane = sc4 >> 3, wcol = (sc4 & 7) * 4;
+  const int wplane = (sc4 * CPT) >> 5, wcol = (sc4 * CPT) & 31;
   // transposed-read addresses: lane 4q + pp of a 16-lane group supplies row q, channels 4 pp .. 4 pp + 3 of its block;
   // the group (lane >> 4) & 1 takes channels 16 .. 31 of the wave's 32, the half lane >> 5 the pixels 8 .. 15 of a k-step
   const int tq = (lane >> 2) & 3, tp = lane & 3, tcb = (lane >> 4) & 1;
   const int a_lane = (wm * PIX + 8 * lh + tq) * 32 + tcb * 16 + tp * 4;
   const int b_lane = PEL + (wn * QROWS + (TWL == 3 ? S * lh * QW : 2 * S * lh * QW) + S * tq) * 32 + tcb * 16 + tp * 4;
 
-  float4 rp[NP], rq[NQ];
+  f32x4 rp[NP], rq[NQ];                                // 16 raw bytes: 4 fp32 or 8 bf16 channels
   unsigned qmask = 0u;                                 // bit i: halo row i of the step in flight is a real pixel
   unsigned pmask = 0u;                                 // same for the P rows (PTR only)
   const bool q_ps = QTR && qs.scale && qs.ss != 0;
@@ -973,29 +987,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     if ((q_ps || p_ps) && live && sn != tab_n) {
       tab_n = sn;
       if (q_ps) {
-        qsc = *reinterpret_cast<const float4*>(qs.scale + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
-        qsh = *reinterpret_cast<const float4*>(qs.shift + (size_t)sn * qs.ss + (qvalid ? (int)(qcl4 >> 2) : 0));
+        const size_t o = (size_t)sn * qs.ss + (qvalid ? qcl : 0);
+        qsc = *reinterpret_cast<const float4*>(qs.scale + o);
+        qsh = *reinterpret_cast<const float4*>(qs.shift + o);
+        if (S16) { qsc2 = *reinterpret_cast<const float4*>(qs.scale + o + 4); qsh2 = *reinterpret_cast<const float4*>(qs.shift + o + 4); }
       }
       if (p_ps) {
-        psc = *reinterpret_cast<const float4*>(p.P.scale + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
-        psh = *reinterpret_cast<const float4*>(p.P.shift + (size_t)sn * p.P.ss + (mvalid ? mc : 0));
+        const size_t o = (size_t)sn * p.P.ss + (mvalid ? mc : 0);
+        psc = *reinterpret_cast<const float4*>(p.P.scale + o);
+        psh = *reinterpret_cast<const float4*>(p.P.shift + o);
+        if (S16) { psc2 = *reinterpret_cast<const float4*>(p.P.scale + o + 4); psh2 = *reinterpret_cast<const float4*>(p.P.shift + o + 4); }
       }
     }
     if (live && sn != desc_n) {
       desc_n = sn;
-      rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.P.ptr + (size_t)sn * HWp * Mch), 0, HWp * Mch * 4,
-                                              0x00020000);
-      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qs.ptr + (size_t)sn * HWq * qs.C), 0, HWq * qs.C * 4,
-                                              0x00020000);
+      rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)p.P.ptr + (size_t)sn * HWp * Mch * ESZ), 0,
+                                              HWp * Mch * ESZ, 0x00020000);
+      rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>((const char*)qs.ptr + (size_t)sn * HWq * qs.C * ESZ), 0,
+                                              HWq * qs.C * ESZ, 0x00020000);
     }
     const unsigned psoff = (unsigned)(spy * p.Wp + spx0) * mC4;
     unsigned pbits = 0u;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const bool pok = live & mvalid & (spy + pr0 + (16 >> TWL) * i < p.Hp);
-      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv0 + pvstep * i : OOB,
-                                                                                       psoff, 0));
-      rp[i] = make_float4(v[0], v[1], v[2], v[3]);
+      const bool pok = live & mvalid & (spy + pr0 + (RP >> TWL) * i < p.Hp);
+      rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, pok ? pv0 + pvstep * i : OOB, psoff, 0));
       pbits |= (unsigned)pok << i;
     }
     pmask = pbits;
@@ -1003,12 +1019,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     unsigned okbits = 0u;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const bool qlive = spx + 16 * i < QROWS;
+      const bool qlive = spx + RP * i < QROWS;
       const int qy = qy0 + (qrj[i] >> 8), qx = qx0 + (qrj[i] & 255);
       const bool ok = live & qvalid & qlive & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
       const unsigned qo = (unsigned)(qy * p.Wq + qx) * qC4 + qcl4;
-      const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? qo : OOB, 0, 0));
-      rq[i] = make_float4(q[0], q[1], q[2], q[3]);
+      rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? qo : OOB, 0, 0));
       okbits |= (unsigned)ok << i;
     }
     qmask = okbits;
@@ -1022,33 +1037,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     return h;
   };
 
+  auto xf = [&](float4 v, const float4& sc, const float4& sh, int act, float lo, float m, int tr) -> float4 {
+    if (tr == 2) v = act_fwd4(v, act);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+  // one staged row segment (4 fp32 or 8 bf16 channels) -> bf16 in LDS at element offset e
+  auto put = [&](__bf16* stage, int e, const f32x4& raw, int tr, const float4& sc, const float4& sh, const float4& sc2,
+                 const float4& sh2, int act, float lo, float m) {
+    if (S16) {
+      const uint4 r = __builtin_bit_cast(uint4, raw);
+      if (tr == 0) {
+        *reinterpret_cast<uint4*>(stage + e) = r;
+      } else {
+        const uint2 a = f32x4_to_bf16(xf(bf16x4_to_f32(make_uint2(r.x, r.y)), sc, sh, act, lo, m, tr));
+        const uint2 b = f32x4_to_bf16(xf(bf16x4_to_f32(make_uint2(r.z, r.w)), sc2, sh2, act, lo, m, tr));
+        *reinterpret_cast<uint4*>(stage + e) = make_uint4(a.x, a.y, b.x, b.y);
+      }
+    } else {
+      float4 v = make_float4(raw[0], raw[1], raw[2], raw[3]);
+      if (tr != 0) v = xf(v, sc, sh, act, lo, m, tr);
+      *reinterpret_cast<wbf16x4*>(stage + e) = to_bf(v);
+    }
+  };
+
   auto commit = [&](__bf16* stage) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      float4 v = rp[i];
-      if (PTR != 0) {
-        if (PTR == 2) v = act_fwd4(v, p.P.act);
-        else { v.x = clamp_lo(v.x, plo); v.y = clamp_lo(v.y, plo); v.z = clamp_lo(v.z, plo); v.w = clamp_lo(v.w, plo); }
-        const float m = ((pmask >> i) & 1u) ? 1.f : 0.f;
-        v.x = (v.x * psc.x + psh.x) * m; v.y = (v.y * psc.y + psh.y) * m;
-        v.z = (v.z * psc.z + psh.z) * m; v.w = (v.w * psc.w + psh.w) * m;
-      }
-      *reinterpret_cast<wbf16x4*>(stage + (wplane * PIX + spx + 16 * i) * 32 + wcol) = to_bf(v);
-    }
+    for (int i = 0; i < NP; ++i)
+      put(stage, (wplane * PIX + spx + RP * i) * 32 + wcol, rp[i], PTR, psc, psh, psc2, psh2, p.P.act, plo,
+          ((pmask >> i) & 1u) ? 1.f : 0.f);
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      if (spx + 16 * i < QROWS) {
-        float4 v = rq[i];
-        if (QTR != 0) {
-          if (QTR == 2) v = act_fwd4(v, qs.act);
-          else { v.x = clamp_lo(v.x, qlo); v.y = clamp_lo(v.y, qlo); v.z = clamp_lo(v.z, qlo); v.w = clamp_lo(v.w, qlo); }
-          const float m = ((qmask >> i) & 1u) ? 1.f : 0.f;
-          v.x = (v.x * qsc.x + qsh.x) * m; v.y = (v.y * qsc.y + qsh.y) * m;
-          v.z = (v.z * qsc.z + qsh.z) * m; v.w = (v.w * qsc.w + qsh.w) * m;
-        }
-        *reinterpret_cast<wbf16x4*>(stage + PEL + (wplane * QROWS + spx + 16 * i) * 32 + wcol) = to_bf(v);
-      }
-    }
+    for (int i = 0; i < NQ; ++i)
+      if (spx + RP * i < QROWS)
+        put(stage, PEL + (wplane * QROWS + spx + RP * i) * 32 + wcol, rq[i], QTR, qsc, qsh, qsc2, qsh2, qs.act, qlo,
+            ((qmask >> i) & 1u) ? 1.f : 0.f);
   };
 
   if (nsteps > 0) {
@@ -1246,6 +1270,15 @@ static int wgrad_check(const MsegWgrad& p) {
   if (!((p.KH == 3 && p.KW == 3) || (p.KH == 2 && p.KW == 2))) return MSEG_EINVAL;
   if (p.NB <= 0 || p.Hp <= 0 || p.Wp <= 0 || p.Hq <= 0 || p.Wq <= 0 || p.stride < 1) return MSEG_EINVAL;
   if (p.precision != MSEG_PREC_F32 && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
+  // tensor storage: P and all Q of one type; bf16 tensors (8 channels per staging load) only with the bf16 kernels
+  if (p.P.dtype != MSEG_ST_F32 && p.P.dtype != MSEG_ST_BF16) return MSEG_EINVAL;
+  for (int i = 0; i < p.nq; ++i)
+    if (p.Q[i].dtype != p.P.dtype) return MSEG_EINVAL;
+  if (p.P.dtype == MSEG_ST_BF16) {
+    if (p.precision != MSEG_PREC_BF16 || (p.P.C & 7)) return MSEG_EINVAL;
+    for (int i = 0; i < p.nq; ++i)
+      if (p.Q[i].C & 7) return MSEG_EINVAL;
+  }
   return MSEG_OK;
 }
 
@@ -1269,6 +1302,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     const WgradSel sel = wgrad_select(p);
     const bool generic = sel.generic_act, per_sample = sel.per_sample;
     const int ptr = sel.ptr, qtr = sel.qtr, tw_log2 = sel.tw_log2;
+    const bool s16 = p.P.dtype == MSEG_ST_BF16;         // bf16 tensor storage (wgrad_check: P and Q agree, bf16 kernels only)
     const dim3 grid((unsigned)tiles * (unsigned)splits * (unsigned)(sel.kind >= 3 ? 1 : p.KH)), block(256);
     if (sel.kind != 0) {
       static bool ident_ready[64] = {false};
@@ -1280,23 +1314,33 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
         ident_ready[devid] = true;
       }
       if (sel.kind == 4) {                             // 3x3 stride-2 convolution (plain P)
-#define MSEG_WB4(T_, Q_) \
-  hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB4(T_, Q_)                                                                                          \
+  do {                                                                                                            \
+    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
+    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
+  } while (0)
 #define MSEG_WB4_Q(T_) do { if (qtr == 0) MSEG_WB4(T_, 0); else if (qtr == 1) MSEG_WB4(T_, 1); else MSEG_WB4(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB4_Q(3); else MSEG_WB4_Q(2);
 #undef MSEG_WB4_Q
 #undef MSEG_WB4
         MSEG_LAUNCH_CHECK();
       } else if (sel.kind == 5) {                      // ConvTranspose2d 2x2 stride 2 (plain Q)
-#define MSEG_WB5(T_, P_) \
-  hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB5(T_, P_)                                                                                          \
+  do {                                                                                                            \
+    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, true>), grid, block, 0, st, p, splits, sps); \
+    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, false>), grid, block, 0, st, p, splits, sps);    \
+  } while (0)
 #define MSEG_WB5_P(T_) do { if (ptr == 0) MSEG_WB5(T_, 0); else if (ptr == 1) MSEG_WB5(T_, 1); else MSEG_WB5(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB5_P(3); else MSEG_WB5_P(2);
 #undef MSEG_WB5_P
 #undef MSEG_WB5
         MSEG_LAUNCH_CHECK();
       } else if (sel.kind == 3) {
-#define MSEG_WB(T_, Q_) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WB(T_, Q_)                                                                                           \
+  do {                                                                                                            \
+    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
+    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
+  } while (0)
 #define MSEG_WB_Q(T_) do { if (qtr == 0) MSEG_WB(T_, 0); else if (qtr == 1) MSEG_WB(T_, 1); else MSEG_WB(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB_Q(3); else MSEG_WB_Q(2);
 #undef MSEG_WB_Q

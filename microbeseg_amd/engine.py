@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, NORM, MODE_CONV, MODE_TCONV, EPI_PLAIN, EPI_SCATTER2X2, MORDER_LINEAR, MORDER_PARITY,
-                   MsegSrc, MsegIgemm, MsegWgrad, check)
+                   ST_F32, ST_BF16, MsegSrc, MsegIgemm, MsegWgrad, check)
 
 BN_EPS = 1e-5       # torch defaults used by the reference (unets.py:127-132)
 BN_MOMENTUM = 0.1
@@ -31,6 +31,11 @@ def _stream():
 
 def _pad4(c):
     return (c + 3) // 4 * 4
+
+
+def _st(t):
+    """storage code (MSEG_ST_*) of an activation tensor"""
+    return ST_BF16 if t.dtype == torch.bfloat16 else ST_F32
 
 
 class Node:
@@ -50,6 +55,7 @@ class Node:
         s = MsegSrc()
         s.ptr = self.z.data_ptr()
         s.C = self.C
+        s.dtype = _st(self.z)
         if transform:
             if self.a is not None:      # consumers read the stored activation: no transcendentals in their K-loops
                 s.ptr = self.a.data_ptr()
@@ -66,6 +72,7 @@ def plain_src(t, C_):
     s = MsegSrc()
     s.ptr = t.data_ptr()
     s.C = C_
+    s.dtype = _st(t)
     return s
 
 
@@ -236,6 +243,106 @@ class precision_scope:
         return False
 
 
+_bf16_storage = True
+
+
+def set_bf16_storage(flag):
+    """bf16 mode: also STORE activations / activation gradients as bf16 (default) or keep fp32 tensors in HBM and round
+    only the matrix-core operands (round 1 behaviour; kept for ablation and for networks without a full set of bf16 kernels)"""
+    global _bf16_storage
+    _bf16_storage = bool(flag)
+
+
+class _Shape:
+    """stand-in for MsegSrc / PackedW in the dispatch mirrors below: only the fields those rules read"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def bf16_storage_ok(spec, N, cin, H, W, training):
+    """Can this network run with bf16 tensor storage?  The bf16-storage forms exist for the bf16 matrix-core kernels, the
+    first-layer / head / normalisation kernels: every convolution launch of the forward pass (and, when a tape is kept, of
+    the backward pass) must map to one of them, channel counts must be multiples of 8 (16-byte staging loads of 8 bf16),
+    and the first layer must take the VALU kernels.  Otherwise bf16 mode keeps fp32 tensors (operand rounding only)."""
+    if spec.pool_method == "max":
+        return False
+
+    def src(c):
+        return _Shape(C=c, scale=None, ss=0, act=0)
+
+    def pack(T, n, k):
+        return _Shape(Npad=_round_up(n, 128), Kpad=_round_up(k, 32))
+
+    def conv_ok(cins, cout, hi, wi, stride):
+        ho, wo = (hi + 2 - 3) // stride + 1, (wi + 2 - 3) // stride + 1
+        c = sum(cins)
+        if any(v % 8 for v in cins) or cout % 8:
+            return False
+        if _bf16_launch([src(v) for v in cins], pack(9, cout, c), N, hi, wi, ho, wo, 3, 3, stride, 1, MODE_CONV, EPI_PLAIN,
+                        MORDER_LINEAR) is None:
+            return False
+        if training:
+            morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
+            if _bf16_launch([src(cout)], pack(9, c, cout), N, ho, wo, hi, wi, 3, 3, stride, 1, MODE_TCONV, EPI_PLAIN,
+                            morder) is None:
+                return False
+            if _wgrad_bf16_ok(src(cout), [src(v) for v in cins], N, ho, wo, hi, wi, 3, 3, stride, 1) is None:
+                return False
+        return True
+
+    def up_ok(ci, co, hi, wi):
+        if ci % 8 or co % 8:
+            return False
+        if _bf16_launch([src(ci)], pack(1, 4 * co, ci), N, hi, wi, hi, wi, 1, 1, 1, 0, MODE_CONV, EPI_SCATTER2X2,
+                        MORDER_LINEAR) is None:
+            return False
+        if training:
+            if _bf16_launch([src(co)], pack(4, ci, co), N, 2 * hi, 2 * wi, hi, wi, 2, 2, 2, 0, MODE_CONV, EPI_PLAIN,
+                            MORDER_LINEAR) is None:
+                return False
+            if _wgrad_bf16_ok(src(ci), [src(co)], N, hi, wi, 2 * hi, 2 * wi, 2, 2, 2, 0) is None:
+                return False
+        return True
+
+    h, w = H, W
+    skips = []
+    c_prev = None
+    for i, e in enumerate(spec.enc):
+        c1o, c1i = e["c1"].conv.weight.shape[:2]
+        if i == 0:
+            if not _first_layer_ok(c1i, c1o, 1) or (training and c1i != 1) or c1o % 8:
+                return False
+        elif not conv_ok([c1i], c1o, h, w, 1):
+            return False
+        c2o = e["c2"].conv.weight.shape[0]
+        if not conv_ok([c1o], c2o, h, w, 1):
+            return False
+        c_prev = c2o
+        if e["pool"] is not None:
+            skips.append((c2o, h, w))
+            if not conv_ok([c2o], c2o, h, w, 2):
+                return False
+            h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    for d in spec.decoders:
+        ch, hh, ww = c_prev, h, w
+        for lv, (cs, hs, wsk) in zip(d["levels"], reversed(skips)):
+            ci, co = lv["up"].conv.weight.shape[:2]
+            if ci != ch or not up_ok(ci, co, hh, ww):
+                return False
+            hh, ww = 2 * hh, 2 * ww
+            c1o = lv["c1"].conv.weight.shape[0]
+            if not conv_ok([co, cs], c1o, hh, ww, 1):
+                return False
+            c2o = lv["c2"].conv.weight.shape[0]
+            if not conv_ok([c1o], c2o, hh, ww, 1):
+                return False
+            ch = c2o
+        if ch % 8:
+            return False
+    return True
+
+
 # ---- thin kernel wrappers ------------------------------------------------------------------------------------
 def _round_up(v, m):
     return (v + m - 1) // m * m
@@ -379,6 +486,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     p.Npad = w.Npad
     p.w = w.bf16().data_ptr() if bf16 else w.t.data_ptr()
     p.precision = 1 if bf16 else 0
+    p.dst_dtype = _st(dst0)                 # bf16 tensor storage: the C ABI accepts it for the bf16 kernels only
     p.bias = _ptr(bias)
     p.dst0 = dst0.data_ptr()
     p.dst1 = _ptr(dst1)
@@ -492,8 +600,8 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
                                           BN_EPS, Cc, node.scale.data_ptr(), node.shift.data_ptr(), _stream()),
                   "bn_eval_coeffs")
             if expensive:
-                check(lib.mseg_activation(node.z.data_ptr(), N, HW, Cc, node.act, node.a.data_ptr(), _stream()),
-                      "activation")
+                check(lib.mseg_activation(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, node.a.data_ptr(),
+                                          _stream()), "activation")
             return
         node.mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         node.rstd = torch.empty(Cc, dtype=torch.float32, device=dev)
@@ -506,7 +614,7 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
         node.rstd = torch.empty(N * ng, dtype=torch.float32, device=dev)
         running_mean = running_var = None
     w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
-    check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
+    check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
                               node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
                               node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
                               _ptr(node.a), w.data_ptr(), _stream()), "norm_stats")
@@ -517,7 +625,7 @@ def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):
     lib = _lib.load()
     N, HW, Cc = node.N, node.H * node.W, node.C
     w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
-    check(lib.mseg_norm_bwd(gy.data_ptr(), node.z.data_ptr(), N, HW, Cc, node.act, node.norm, _ptr(gamma),
+    check(lib.mseg_norm_bwd(gy.data_ptr(), node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, node.norm, _ptr(gamma),
                             node.mean.data_ptr(), node.rstd.data_ptr(), gy.data_ptr(), _ptr(dgamma), _ptr(dbeta),
                             _ptr(dbias), _ptr(node.a), w.data_ptr(), _stream()), "norm_bwd")
     return gy
@@ -589,7 +697,8 @@ def _first_layer_ok(cin, cout, stride):
     return stride == 1 and 1 <= cin <= 4 and cout % 4 == 0 and cout <= 256 and 256 % (cout // 4) == 0
 
 
-def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
+def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch.float32):
+    """`st`: storage type of the layer's output z (torch.float32, or torch.bfloat16 in bf16-storage mode)"""
     conv = spec.conv
     n0 = in_nodes[0]
     N, Hi, Wi = n0.N, n0.H, n0.W
@@ -603,7 +712,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
         assert cin == cin_total
         wp = pack_weight(conv.weight, 4, cout, cin, 1, 4, cout * 4, merge_taps=True, kind="fwd")
         Ho, Wo = 2 * Hi, 2 * Wi
-        z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+        z = torch.empty((N, Ho, Wo, cout), dtype=st, device=dev)
         igemm(srcs, wp, bias, N, Hi, Wi, Hi, Wi, 1, 1, 1, 0, MODE_CONV, 4 * cout, z, cout,
               epi=EPI_SCATTER2X2, Cq=cout)
         act = ACT["none"]
@@ -615,11 +724,11 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None):
         else:
             assert _pad4(cin) == cin_total, (cin, cin_total)   # network input is zero-padded to 4 channels
         Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
-        z = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=dev)
+        z = torch.empty((N, Ho, Wo, cout), dtype=st, device=dev)
         if first_layer_cin is not None and _first_layer_ok(cin, cout, stride):
             # raw network input, 9..36 MACs per output: HBM-bound VALU kernel instead of a 32-channel MFMA K-step
             check(_lib.load().mseg_first_conv_fwd(n0.z.data_ptr(), wt.contiguous().data_ptr(), bias.data_ptr(), N, Hi,
-                                                  Wi, cin, cout, z.data_ptr(), _stream()), "first_conv_fwd")
+                                                  Wi, cin, cout, z.data_ptr(), _st(z), _stream()), "first_conv_fwd")
         else:
             wp = pack_weight(conv.weight, 9, cout, cin, 1, cin * 9, 9, kind="fwd")
             igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
@@ -678,26 +787,29 @@ def forward(spec, x, training, keep_tape, ws):
     tape = Tape() if keep_tape else None
     if tape is not None:
         tape.x4 = xin
+    # bf16 mode: activations and their gradients are STORED as bf16 when every launch of this network has a bf16 kernel
+    st = torch.bfloat16 if (_precision == "bf16" and _bf16_storage and
+                            bf16_storage_ok(spec, N, cin, H, W, keep_tape)) else torch.float32
 
     cur = xin
     skips = []
     for i, e in enumerate(spec.enc):
-        cur = _run_conv(e["c1"], [cur], training, ws, tape, first_layer_cin=cin if i == 0 else None)
-        cur = _run_conv(e["c2"], [cur], training, ws, tape)
+        cur = _run_conv(e["c1"], [cur], training, ws, tape, first_layer_cin=cin if i == 0 else None, st=st)
+        cur = _run_conv(e["c2"], [cur], training, ws, tape, st=st)
         if e["pool"] is not None:
             skips.append(cur)
             if e["pool"] == "max":
                 cur = _run_maxpool(cur, tape)
             else:
-                cur = _run_conv(e["pool"], [cur], training, ws, tape)
+                cur = _run_conv(e["pool"], [cur], training, ws, tape, st=st)
     bottom = cur
     outs = []
     for d in spec.decoders:
         cur = bottom
         for lv, skip in zip(d["levels"], reversed(skips)):
-            up = _run_conv(lv["up"], [cur], training, ws, tape)
-            cur = _run_conv(lv["c1"], [up, skip], training, ws, tape)
-            cur = _run_conv(lv["c2"], [cur], training, ws, tape)
+            up = _run_conv(lv["up"], [cur], training, ws, tape, st=st)
+            cur = _run_conv(lv["c1"], [up, skip], training, ws, tape, st=st)
+            cur = _run_conv(lv["c2"], [cur], training, ws, tape, st=st)
         hc = d["head"].conv
         co = hc.weight.shape[0]
         out = torch.empty((N, co, H, W), dtype=torch.float32, device=dev)
@@ -744,15 +856,15 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
         co = hc.weight.shape[0]
         if go is None:
             go = torch.zeros((node.N, co, node.H, node.W), dtype=torch.float32, device=node.z.device)
-        go = go.contiguous()
+        go = go.contiguous().float()
         gy = torch.empty_like(node.z)
         dW = _grad_buf(hc.weight, direct)
         db = _grad_buf(hc.bias, direct)
         w = ws.get("head", lib.mseg_head_bwd_workspace_bytes(node.N, node.H * node.W, node.C, co))
         s = node.src()
         check(lib.mseg_head_bwd(C.byref(s), node.N, node.H * node.W, hc.weight.detach().data_ptr(), co,
-                                go.data_ptr(), gy.data_ptr(), dW.data_ptr(), db.data_ptr(), w.data_ptr(), _stream()),
-              "head_bwd")
+                                go.data_ptr(), gy.data_ptr(), _st(gy), dW.data_ptr(), db.data_ptr(), w.data_ptr(),
+                                _stream()), "head_bwd")
         assert node.grad is None
         node.grad = gy
         grads[id(hc.weight)] = dW
@@ -804,7 +916,7 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
             is_first = i0 is tape.x4
             if is_first and cin == 1 and _first_layer_ok(cin, cout, stride):
                 w1 = ws.get("first_wgrad", lib.mseg_first_wgrad_workspace_bytes(N, node.H, node.W, cout))
-                check(lib.mseg_first_wgrad(i0.z.data_ptr(), dz.data_ptr(), N, node.H, node.W, cout, dW.data_ptr(),
+                check(lib.mseg_first_wgrad(i0.z.data_ptr(), dz.data_ptr(), _st(dz), N, node.H, node.W, cout, dW.data_ptr(),
                                            w1.data_ptr(), _stream()), "first_wgrad")
             else:
                 wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride,

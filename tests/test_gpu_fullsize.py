@@ -39,11 +39,13 @@ def _hip_step(net, x, gos, dev, precision="fp32"):
         outs = outs if isinstance(outs, tuple) else (outs,)
         torch.autograd.backward(outs, [g.to(dev) for g in gos])
         masks = tr.relu_masks()
+        _hip_step.stored_bf16 = tr.nodes[0].z.dtype == torch.bfloat16
     return [o.detach().cpu() for o in outs], masks
 
 
-def _oracle_step(sd, x, gos, ut, act, norm, dtype, masks=None, trace=None, rule=None):
+def _oracle_step(sd, x, gos, ut, act, norm, dtype, masks=None, trace=None, rule=None, storage=False):
     from oracle import unet_ref
+    unet_ref.BF16_STORAGE = bool(storage and rule is not None)
     params = {k: (v.clone().to(dtype).requires_grad_(True) if v.is_floating_point() and "running" not in k
                   else (v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
     unet_ref.RELU_MASKS = iter(masks) if masks is not None else None
@@ -55,6 +57,7 @@ def _oracle_step(sd, x, gos, ut, act, norm, dtype, masks=None, trace=None, rule=
         torch.autograd.backward(ref, [g.to(dtype) for g in gos])
     finally:
         unet_ref.RELU_MASKS = unet_ref.RELU_TRACE = unet_ref.BF16_RULE = None
+        unet_ref.BF16_STORAGE = False
     return params, [r.detach() for r in ref]
 
 
@@ -150,8 +153,10 @@ def test_config2_full_network_320_bf16_vs_bf16_oracle(dev):
     x = torch.rand(2, 1, 320, 320) * 2 - 1
     gos = [torch.randn(2, 1, 320, 320) for _ in range(2)]
     outs, masks = _hip_step(net, x, gos, dev, precision="bf16")
+    assert _hip_step.stored_bf16       # configs[2]: activations and their gradients live in HBM as bf16
     trace = []
-    p16, r16 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks, trace=trace, rule=bf16_rule)
+    p16, r16 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks, trace=trace, rule=bf16_rule,
+                            storage=True)
     p32, r32 = _oracle_step(sd, x, gos, "DU", "relu", "bn", torch.float32, masks=masks)
 
     def l2(a, b):

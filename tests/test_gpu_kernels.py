@@ -307,7 +307,7 @@ def test_head_forward_backward(eng, Cc, Co):
     dW, db = torch.empty((Co, Cc), device="cuda"), torch.empty(Co, device="cuda")
     wsb = torch.empty(lib.mseg_head_bwd_workspace_bytes(N, H * W, Cc, Co), dtype=torch.uint8, device="cuda")
     god = gy.cuda()
-    _lib.check(lib.mseg_head_bwd(C.byref(s), N, H * W, wd.data_ptr(), Co, god.data_ptr(), gx.data_ptr(), dW.data_ptr(),
+    _lib.check(lib.mseg_head_bwd(C.byref(s), N, H * W, wd.data_ptr(), Co, god.data_ptr(), gx.data_ptr(), 0, dW.data_ptr(),
                                  db.data_ptr(), wsb.data_ptr(), stream))
     assert rel_err(nchw(gx.cpu()), xin.grad) < TOL
     assert rel_err(dW.cpu(), w.grad.reshape(Co, Cc)) < TOL
@@ -330,8 +330,13 @@ def test_first_layer_kernels(eng, N, Cin, Cout, H, W):
     z = torch.full((N, H, W, Cout), float("nan"), device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     wd, bd = w.detach().cuda(), b.cuda()          # keep the device copies alive across the asynchronous launch
-    _lib.check(lib.mseg_first_conv_fwd(x4.data_ptr(), wd.data_ptr(), bd.data_ptr(), N, H, W, Cin, Cout, z.data_ptr(),
+    _lib.check(lib.mseg_first_conv_fwd(x4.data_ptr(), wd.data_ptr(), bd.data_ptr(), N, H, W, Cin, Cout, z.data_ptr(), 0,
                                        st), "first_conv_fwd")
+    if Cout % 8 == 0:                              # bf16 storage of z: the same values rounded to bf16
+        z16 = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.mseg_first_conv_fwd(x4.data_ptr(), wd.data_ptr(), bd.data_ptr(), N, H, W, Cin, Cout, z16.data_ptr(),
+                                           1, st), "first_conv_fwd")
+        assert torch.equal(z16, z.to(torch.bfloat16))
     assert rel_err(nchw(z.cpu()), ref.detach()) < TOL
     if Cin == 1:
         gy = rnd(g, N, Cout, H, W)
@@ -339,9 +344,16 @@ def test_first_layer_kernels(eng, N, Cin, Cout, H, W):
         ws = torch.empty(lib.mseg_first_wgrad_workspace_bytes(N, H, W, Cout), dtype=torch.uint8, device="cuda")
         dW = torch.full((Cout, 1, 3, 3), float("nan"), device="cuda")
         gyd = nhwc(gy).cuda()
-        _lib.check(lib.mseg_first_wgrad(x4.data_ptr(), gyd.data_ptr(), N, H, W, Cout, dW.data_ptr(), ws.data_ptr(), st),
+        _lib.check(lib.mseg_first_wgrad(x4.data_ptr(), gyd.data_ptr(), 0, N, H, W, Cout, dW.data_ptr(), ws.data_ptr(), st),
                    "first_wgrad")
         assert rel_err(dW.cpu(), w.grad) < TOL
+        g16 = gyd.to(torch.bfloat16)               # bf16 storage of dz: exact on the rounded operand
+        ref2 = F.conv2d(x, w.detach().clone().requires_grad_(True), b, padding=1)
+        w2 = torch.zeros_like(w).requires_grad_(True)
+        F.conv2d(x, w2, None, padding=1).backward(nchw(g16.float().cpu()))
+        _lib.check(lib.mseg_first_wgrad(x4.data_ptr(), g16.data_ptr(), 1, N, H, W, Cout, dW.data_ptr(), ws.data_ptr(), st),
+                   "first_wgrad")
+        assert rel_err(dW.cpu(), w2.grad) < TOL
 
 
 def test_halo_kernels_beyond_2gib(eng):
@@ -650,3 +662,162 @@ def test_repack_all_equals_single_packs(eng):
         assert torch.equal(e.t, once.t)
         if e._t16 is not None:
             assert torch.equal(e._t16, once.t.to(torch.bfloat16))
+
+
+# ---- bf16 tensor STORAGE (MSEG_ST_BF16: BASELINE configs[2], "bf16 forward / backward") -----------------------------------
+def _b16(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("norm", ["bn", "gn", "in"])
+@pytest.mark.parametrize("act", ["relu", "mish"])
+def test_bf16_storage_norm_forward_backward(eng, norm, act):
+    """normalisation statistics / backward on bf16-stored z, gy, dz (8 channels per thread): the kernel computes in fp32 on
+    the values as stored; against torch on the SAME rounded inputs, output dz compared after rounding to bf16."""
+    from microbeseg_amd import _lib
+    from microbeseg_amd._lib import ACT, NORM
+    lib = _lib.load()
+    N, Cc, H, W = 3, 64, 12, 20
+    g = torch.Generator().manual_seed(5)
+    z16 = _b16(rnd(g, N, Cc, H, W))
+    gy16 = _b16(rnd(g, N, Cc, H, W))
+    gamma, beta = rnd(g, Cc) * 0.3 + 1, rnd(g, Cc) * 0.1
+    z = z16.float().requires_grad_(True)
+    a = _act_cpu(z, act)
+    if norm == "bn":
+        y = F.batch_norm(a, None, None, gamma, beta, True, 0.1, 1e-5)
+    elif norm == "gn":
+        y = F.group_norm(a, 8, gamma, beta, 1e-5)
+    else:
+        y = F.instance_norm(a, eps=1e-5)
+    y.backward(gy16.float())
+    zd, gyd = nhwc(z16).cuda(), nhwc(gy16).cuda()
+    ss = 0 if norm == "bn" else Cc
+    nsc = Cc if norm == "bn" else N * Cc
+    ng = Cc if norm == "bn" else (N * 8 if norm == "gn" else N * Cc)
+    scale, shift = torch.empty(nsc, device="cuda"), torch.empty(nsc, device="cuda")
+    mean, rstd = torch.empty(ng, device="cuda"), torch.empty(ng, device="cuda")
+    aout = torch.empty_like(zd) if act == "mish" else None
+    ws = torch.empty(lib.mseg_norm_workspace_bytes(N, H * W, Cc), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    gd, bd = (gamma.cuda(), beta.cuda()) if norm != "in" else (None, None)
+    P = lambda t: None if t is None else t.data_ptr()
+    _lib.check(lib.mseg_norm_stats(zd.data_ptr(), N, H * W, Cc, 1, ACT[act], NORM[norm], P(gd), P(bd), 1e-5,
+                                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, None, 0.1,
+                                   P(aout), ws.data_ptr(), st), "norm_stats")
+    # y = a * scale + shift reproduces the normalised tensor (a as stored: bf16 for the materialised activation)
+    a_used = nchw(aout.float().cpu()) if aout is not None else a.detach()
+    sc = scale.cpu().reshape((1, Cc, 1, 1) if norm == "bn" else (N, Cc, 1, 1))
+    sh = shift.cpu().reshape(sc.shape)
+    tol_y = 1e-4 if aout is None else 2e-2       # a rounded to bf16 shifts the statistics by ~2^-9 relative
+    assert rel_err(a_used * sc + sh, y.detach()) < tol_y
+    dzd = torch.empty_like(zd)
+    dgamma, dbeta, dbias = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    _lib.check(lib.mseg_norm_bwd(gyd.data_ptr(), zd.data_ptr(), N, H * W, Cc, 1, ACT[act], NORM[norm], P(gd),
+                                 mean.data_ptr(), rstd.data_ptr(), dzd.data_ptr(), P(dgamma) if norm != "in" else None,
+                                 P(dbeta) if norm != "in" else None, dbias.data_ptr(), P(aout), ws.data_ptr(), st), "norm_bwd")
+    tol = 1e-2 if aout is not None else 4e-3      # one bf16 rounding of dz (2^-9) on top of the fp32 arithmetic
+    assert rel_err(nchw(dzd.float().cpu()), z.grad) < tol
+    assert rel_err(dbias.cpu(), nchw(dzd.float().cpu()).sum((0, 2, 3))) < 1e-4      # sum of dz AS STORED
+    if norm != "in":
+        assert rel_err(dbeta.cpu(), gy16.float().sum((0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,two_src", [(2, 64, 64, 16, 32, False), (1, 96, 160, 32, 40, False),
+                                                     (2, 128, 64, 16, 16, True), (1, 256, 256, 16, 16, False),
+                                                     (3, 64, 128, 30, 64, False), (2, 512, 512, 16, 16, False)])
+def test_bf16_storage_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
+    """bf16 sources AND bf16 destinations through the bf16 halo kernels (8 channels per staging thread): forward with
+    norm-on-load sources, data gradient with a plain bf16 operand, accumulate into a bf16 destination."""
+    g = torch.Generator().manual_seed(300 + Cin + H)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    scale, shift = rnd(g, Cin) * 0.3 + 1.0, rnd(g, Cin) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z16.float(), "relu", scale, shift, False)), _bf(w), b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+
+    def node16(zz, sc, sh):
+        n = _mk_node(eng, zz.float(), "relu", sc, sh)
+        n.z = n.z.to(torch.bfloat16)
+        return n
+    if two_src:
+        c0 = Cin // 2
+        nodes = [node16(z16[:, :c0], scale[:c0], shift[:c0]), node16(z16[:, c0:], scale[c0:], shift[c0:])]
+    else:
+        nodes = [node16(z16, scale, shift)]
+    srcs = [n.src() for n in nodes]
+    assert all(s.dtype == 1 for s in srcs)
+    eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+    got = nchw(out.float().cpu())
+    assert rel_err(got, ref) < 6e-3                      # the bf16 rounding of the stored result
+    assert rel_err(got, _bf(ref)) < 6e-3
+    # data gradient: plain bf16 operand, accumulate into bf16 destination 0, plain store into bf16 destination 1
+    gy16 = _b16(rnd(g, N, Cout, H, W))
+    refn = nhwc(F.conv_transpose2d(gy16.float(), _bf(w), None, padding=1))
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    base = _b16(rnd(g, N, H, W, Cin))
+    c0 = (Cin // 2 + 7) // 8 * 8
+    d0 = base[..., :c0].contiguous().cuda()
+    d1 = torch.full((N, H, W, Cin - c0), float("nan"), device="cuda", dtype=torch.bfloat16)
+    dz = nhwc(gy16).cuda()
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, c0, acc0=1,
+              dst1=d1, ld1=Cin - c0, acc1=0, split=c0, precision="bf16")
+    assert rel_err(d0.float().cpu(), refn[..., :c0] + base[..., :c0].float()) < 6e-3
+    assert rel_err(d1.float().cpu(), refn[..., c0:]) < 6e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 128, 16, 16), (1, 128, 72, 24, 40), (4, 32, 64, 32, 32)])
+def test_bf16_storage_strided_and_transposed(eng, N, Cin, Cout, H, W):
+    """bf16 storage through the bf16 gather kernel: stride-2 convolution (norm-on-load source) and ConvTranspose2d as a
+    1x1 GEMM with the scatter epilogue."""
+    g = torch.Generator().manual_seed(41 + Cin)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    scale, shift = rnd(g, Cin) * 0.3 + 1.0, rnd(g, Cin) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    xin = _bf(_transform_cpu(z16.float(), "relu", scale, shift, False))
+    ref = F.conv2d(xin, _bf(w), b, stride=2, padding=1)
+    node = _mk_node(eng, z16.float(), "relu", scale, shift)
+    node.z = node.z.to(torch.bfloat16)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+    assert rel_err(nchw(out.float().cpu()), ref) < 6e-3
+    wt, bt = rnd(g, Cin, Cout, 2, 2) / (Cin ** 0.5), rnd(g, Cout)
+    reft = F.conv_transpose2d(xin, _bf(wt), bt, stride=2)
+    wpt = eng.pack_weight(wt.cuda(), 4, Cout, Cin, 1, 4, Cout * 4, merge_taps=True)
+    outt = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    eng.igemm([node.src()], wpt, bt.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, outt, Cout,
+              epi=eng.EPI_SCATTER2X2, Cq=Cout, precision="bf16")
+    assert rel_err(nchw(outt.float().cpu()), reft) < 6e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,two_src,act", [(2, 64, 64, 16, 16, False, "relu"), (3, 72, 40, 16, 12, False, "relu"),
+                                                        (2, 128, 64, 16, 16, True, "relu"), (2, 64, 64, 24, 32, False, "mish")])
+def test_bf16_storage_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
+    """weight gradient of a 3x3 stride-1 conv from bf16-stored dz (plain) and z (norm-on-load): exact against torch on the
+    rounded operands up to the fp32 accumulation order."""
+    g = torch.Generator().manual_seed(9 + Cin + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    scale, shift = rnd(g, Cin) * 0.3 + 1, rnd(g, Cin) * 0.1
+    xin = _bf(_transform_cpu(z16.float(), act, scale, shift, False))
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    gy16 = _b16(rnd(g, N, Cout, H, W))
+    F.conv2d(xin, w, None, padding=1).backward(gy16.float())
+
+    def node16(zz, sc, sh):
+        n = _mk_node(eng, zz.float(), act, sc, sh)
+        n.z = n.z.to(torch.bfloat16)
+        return n
+    if two_src:
+        c0 = Cin // 2
+        nodes = [node16(z16[:, :c0], scale[:c0], shift[:c0]), node16(z16[:, c0:], scale[c0:], shift[c0:])]
+    else:
+        nodes = [node16(z16, scale, shift)]
+    qs = [n.src() for n in nodes]
+    dz = nhwc(gy16).cuda()
+    dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    eng.wgrad(eng.plain_src(dz, Cout), qs, dW, N, H, W, H, W, 3, 3, 1, 1, eng.Workspace(torch.device("cuda")),
+              precision="bf16")
+    assert rel_err(dW.cpu(), w.grad) < 5e-4

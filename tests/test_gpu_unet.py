@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import VARIANTS, bf16_rule as _bf16_rule, grad_floor, load_npz, rel_err, state_from, variant
+from helpers import VARIANTS, NodeTrace, bf16_rule as _bf16_rule, grad_floor, load_npz, rel_err, state_from, variant
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -300,15 +300,19 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
     net.train()
     engine.set_precision("bf16")
     try:
-        outs = net(x.to(dev))
-        outs = outs if isinstance(outs, tuple) else (outs,)
-        gos = [torch.randn(o.shape) for o in outs]
-        torch.autograd.backward(outs, [g.to(dev) for g in gos])
+        with NodeTrace() as tr:
+            outs = net(x.to(dev))
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            gos = [torch.randn(o.shape) for o in outs]
+            torch.autograd.backward(outs, [g.to(dev) for g in gos])
+            stored_bf16 = tr.nodes[0].z.dtype == torch.bfloat16
     finally:
         engine.set_precision("fp32")
+    assert stored_bf16          # these networks have bf16 kernels for every launch: activations are stored as bf16
 
     def oracle(rule):
         unet_ref.BF16_RULE = rule
+        unet_ref.BF16_STORAGE = stored_bf16
         try:
             params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
                       for k, v in sd.items()}
@@ -317,6 +321,7 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
             torch.autograd.backward(ref, gos)
         finally:
             unet_ref.BF16_RULE = None
+            unet_ref.BF16_STORAGE = False
         return params, ref
 
     p16, r16 = oracle(_bf16_rule)
