@@ -42,27 +42,34 @@ extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
   return ((size_t)N * g.chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
 }
 
-// V consecutive channels (V = 4: fp32 storage, V = 8: bf16 storage) at element offset e
+// V consecutive channels (V = 4: fp32 storage, V = 8: bf16 storage) at element offset e.  Loaded values stay in their 16 raw
+// bytes (4 registers) until `get` widens them right before use: a thread keeps U x 3 such loads in flight, and widening
+// them all at load time would double the registers of the bf16 form (2 waves per SIMD instead of 4).
 template <bool S16>
 struct NormVec {
   static constexpr int V = S16 ? 8 : 4;
-  float v[V];
+  uint4 raw;
   __device__ __forceinline__ void load(const void* base, size_t e) {
+    if (S16) raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + e);
+    else raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(base) + e);
+  }
+  __device__ __forceinline__ void get(float (&v)[V]) const {
     if (S16) {
-      const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + e);
-      v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
-      v[V - 4] = bf16_lo(r.z); v[V - 3] = bf16_hi(r.z); v[V - 2] = bf16_lo(r.w); v[V - 1] = bf16_hi(r.w);
+      v[0] = bf16_lo(raw.x); v[1] = bf16_hi(raw.x); v[2] = bf16_lo(raw.y); v[3] = bf16_hi(raw.y);
+      v[V - 4] = bf16_lo(raw.z); v[V - 3] = bf16_hi(raw.z); v[V - 2] = bf16_lo(raw.w); v[V - 1] = bf16_hi(raw.w);
     } else {
-      const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + e);
-      v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+      v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
     }
   }
-  __device__ __forceinline__ void store(void* base, size_t e) const {
+  // stores v (rounding to bf16 for S16) and returns the values AS STORED in v
+  static __device__ __forceinline__ void put(void* base, size_t e, float (&v)[V]) {
     if (S16) {
       uint4 r;
       r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
       r.z = pack_bf16x2(v[V - 4], v[V - 3]); r.w = pack_bf16x2(v[V - 2], v[V - 1]);
       *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + e) = r;
+      v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+      v[V - 4] = bf16_lo(r.z); v[V - 3] = bf16_hi(r.z); v[V - 2] = bf16_lo(r.w); v[V - 1] = bf16_hi(r.w);
     } else {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + e) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
       }
       // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
       // one load pair per trip left the pass latency-bound at ~3 TB/s
-      constexpr int U = 4;
+      constexpr int U = (S16 && (MODE == 1 || MODE == 2)) ? 2 : 4;   // measured: the 2-3 operand bf16 passes need the registers
       for (int r = row_begin + r0; r < row_end; r += rpi * U) {
         NormVec<S16> zv[U], gv[U], av[U];
         bool ok[U];
@@ -130,31 +137,33 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
         for (int u = 0; u < U; ++u) {
           if (!ok[u]) continue;
           const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
-          NormVec<S16> a4;
-          if ((MODE == 1 || MODE == 2) && aio) a4 = av[u];
+          float zf[V], a4[V];
+          zv[u].get(zf);
+          if ((MODE == 1 || MODE == 2) && aio) av[u].get(a4);
           else {
 #pragma unroll
-            for (int j = 0; j < V; ++j) a4.v[j] = act_fwd(zv[u].v[j], act);
+            for (int j = 0; j < V; ++j) a4[j] = act_fwd(zf[j], act);
           }
-          if ((MODE == 0 || MODE == 3) && aio) {
-            a4.store(aio, off);
-            if (S16) a4.load(aio, off);      // the consumers read the ROUNDED activation: the statistics describe that
-          }
+          if ((MODE == 0 || MODE == 3) && aio)
+            NormVec<S16>::put(aio, off, a4);      // the consumers read the ROUNDED activation: the statistics describe that
           if (MODE == 3) continue;
           if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) { s0[j] += a4.v[j]; s1[j] += (double)a4.v[j] * a4.v[j]; }
-          } else if (MODE == 1) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) { s0[j] += gv[u].v[j]; s1[j] += (double)gv[u].v[j] * a4.v[j]; }
+            for (int j = 0; j < V; ++j) { s0[j] += a4[j]; s1[j] += (double)a4[j] * a4[j]; }
           } else {
-            NormVec<S16> d;
+            float gf[V];
+            gv[u].get(gf);
+            if (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < V; ++j)
-              d.v[j] = (a1[j] * gv[u].v[j] + a2[j] * a4.v[j] + a3[j]) * act_bwd(zv[u].v[j], act);
-            d.store(dz, off);
+              for (int j = 0; j < V; ++j) { s0[j] += gf[j]; s1[j] += (double)gf[j] * a4[j]; }
+            } else {
+              float d[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) s0[j] += S16 ? (float)(__bf16)d.v[j] : d.v[j];     // sum of dz as stored
+              for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * act_bwd(zf[j], act);
+              NormVec<S16>::put(dz, off, d);      // d now holds dz as stored
+#pragma unroll
+              for (int j = 0; j < V; ++j) s0[j] += d[j];
+            }
           }
         }
       }
