@@ -476,9 +476,20 @@ def main():
         a2 = copy.copy(args)
         a2.precision, a2.size, a2.graph = "bf16", 320, False
         a2.steps, a2.warmup = max(args.steps, 10), max(args.warmup, 3)
-        blk, net2 = train_metric(a2, dev, 1, 0, timing=not args.no_kernel_timing)
+        # at ~58 ms per step the ~1300 event records of the kernel bracketing make the step host-bound, so this block takes
+        # its `value` from a run WITHOUT bracketing and the kernel table / roofline from a second, bracketed run
+        blk, net2 = train_metric(a2, dev, 1, 0, timing=False)
         del net2
         torch.cuda.empty_cache()
+        if not args.no_kernel_timing:
+            timed, net2 = train_metric(a2, dev, 1, 0, timing=True)
+            del net2
+            torch.cuda.empty_cache()
+            blk["kernel_timing"] = "separate bracketed pass of %d steps (%.3f ms/step with HIP-event bracketing)" % (
+                a2.steps, timed["ms_per_step"])
+            for key in ("roofline", "kernels"):
+                if key in timed:
+                    blk[key] = timed[key]
         engine.set_precision(args.precision)
         out["bf16_320"] = blk
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -195,18 +195,33 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = 0.f;
         if (e_d16) {
-          __bf16* const d = reinterpret_cast<__bf16*>(dst) + base;
+          // bf16 destination: a lane holds ONE channel of 16 rows, i.e. 2-byte stores.  Lanes 2k / 2k+1 (channels n, n+1;
+          // bf16 storage has even channel counts) swap half of their values through a DPP quad permute, so that the even
+          // lane stores the channel PAIR of the even accumulator rows and the odd lane that of the odd rows: 8 dword
+          // stores (and 8 dword read-modify-write loads) per lane instead of 16 short ones.
+          const bool odd = li & 1;
+          __bf16* const d = reinterpret_cast<__bf16*>(dst) + (base - (odd ? 1 : 0));      // first channel of the pair
+          unsigned oldw[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) oldw[q] = 0u;
           if (accf) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int q = 0; q < 8; ++q) {
+              const int r = 2 * q + (odd ? 1 : 0);
               const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (row < rows_left) old[r] = (float)d[(unsigned)(row * step)];
+              if (row < rows_left) oldw[q] = *reinterpret_cast<const unsigned*>(d + (unsigned)(row * step));
             }
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int q = 0; q < 8; ++q) {
+            const float mine_e = acc[a][b][2 * q] + bias, mine_o = acc[a][b][2 * q + 1] + bias;
+            // the even lane keeps row 2q and hands row 2q+1 to its neighbour; the odd lane the other way round
+            const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+            const float lo = (odd ? got : keep) + bf16_lo(oldw[q]), hi = (odd ? keep : got) + bf16_hi(oldw[q]);
+            const int r = 2 * q + (odd ? 1 : 0);
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < rows_left) d[(unsigned)(row * step)] = (__bf16)(acc[a][b][r] + bias + old[r]);
+            if (row < rows_left) *reinterpret_cast<unsigned*>(d + (unsigned)(row * step)) = pack_bf16x2(lo, hi);
           }
           continue;
         }
@@ -1784,6 +1799,11 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const bool s16 = p.src[0].dtype == MSEG_ST_BF16;
   if (p.nsrc > 1 && p.src[1].dtype != p.src[0].dtype) return MSEG_EINVAL;
   if ((s16 || p.dst_dtype == MSEG_ST_BF16) && p.precision != MSEG_PREC_BF16) return MSEG_EINVAL;
+  if (p.dst_dtype == MSEG_ST_BF16) {        // the epilogue stores channel PAIRS (4 bytes) of a bf16 destination
+    if ((p.Ngemm | p.ld0 | p.ld1 | p.Cq) & 1) return MSEG_EINVAL;
+    if (p.split < p.Ngemm && (p.split & 1)) return MSEG_EINVAL;
+    if (((uintptr_t)p.dst0 | (uintptr_t)p.dst1) & 3) return MSEG_EINVAL;
+  }
   if (p.epi == MSEG_EPI_SCATTER2X2) {
     if (p.Cq <= 0 || p.Ngemm != 4 * p.Cq || p.morder != MSEG_MORDER_LINEAR) return MSEG_EINVAL;
   } else if (p.epi == MSEG_EPI_PLAIN) {
