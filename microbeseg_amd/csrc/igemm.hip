@@ -1102,9 +1102,9 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
       const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
       rsc = *reinterpret_cast<const float4*>(scp + o);
       rsh = *reinterpret_cast<const float4*>(shp + o);
-      if (S16) {                                     // g_ident_* hold 4 entries: the identity needs no second quad
-        rsc2 = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc;
-        rsh2 = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh;
+      if (S16) {                                     // channels 4..7 of this thread (the identity tables are per channel too)
+        rsc2 = *reinterpret_cast<const float4*>(scp + o + 4);
+        rsh2 = *reinterpret_cast<const float4*>(shp + o + 4);
       }
     }
   };
@@ -1340,9 +1340,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
       const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl;
       rsc = *reinterpret_cast<const float4*>(scp + o);
       rsh = *reinterpret_cast<const float4*>(shp + o);
-      if (S16) {                                     // g_ident_* hold 4 entries: the identity needs no second quad
-        rsc2 = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc;
-        rsh2 = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh;
+      if (S16) {                                     // channels 4..7 of this thread (the identity tables are per channel too)
+        rsc2 = *reinterpret_cast<const float4*>(scp + o + 4);
+        rsh2 = *reinterpret_cast<const float4*>(shp + o + 4);
       }
     }
   };
@@ -1577,8 +1577,8 @@ __global__ __launch_bounds__(256) void igemm_fast_bf16_kernel(const MsegIgemm p)
           rsc[i] = *reinterpret_cast<const float4*>(scp + o);
           rsh[i] = *reinterpret_cast<const float4*>(shp + o);
           if (S16) {
-            rsc2[i] = has_aff ? *reinterpret_cast<const float4*>(scp + o + 4) : rsc[i];
-            rsh2[i] = has_aff ? *reinterpret_cast<const float4*>(shp + o + 4) : rsh[i];
+            rsc2[i] = *reinterpret_cast<const float4*>(scp + o + 4);
+            rsh2[i] = *reinterpret_cast<const float4*>(shp + o + 4);
           }
         }
       }

@@ -19,10 +19,10 @@
 #define WH_LDS 64
 
 // identity affine for operands without tables (filled once per device by the launcher)
-__device__ float g_wg_ident_scale[4];
-__device__ float g_wg_ident_shift[4];
+__device__ float g_wg_ident_scale[8];
+__device__ float g_wg_ident_shift[8];
 __global__ void wgrad_init_ident_kernel() {
-  if (threadIdx.x < 4) { g_wg_ident_scale[threadIdx.x] = 1.f; g_wg_ident_shift[threadIdx.x] = 0.f; }
+  if (threadIdx.x < 8) { g_wg_ident_scale[threadIdx.x] = 1.f; g_wg_ident_shift[threadIdx.x] = 0.f; }
 }
 
 // KWT = taps handled by one workgroup (= one kernel row ky = blockIdx.z): 3 for the 3x3 convs, 2 for the 2x2 convT.
@@ -932,20 +932,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     const float* a = p.P.scale ? p.P.scale + (mvalid ? mc : 0) : g_wg_ident_scale;
     const float* b = p.P.scale ? p.P.shift + (mvalid ? mc : 0) : g_wg_ident_shift;
     psc = *reinterpret_cast<const float4*>(a); psh = *reinterpret_cast<const float4*>(b);
-    if (S16) {
-      psc2 = p.P.scale ? *reinterpret_cast<const float4*>(a + 4) : psc;
-      psh2 = p.P.scale ? *reinterpret_cast<const float4*>(b + 4) : psh;
-    }
+    if (S16) { psc2 = *reinterpret_cast<const float4*>(a + 4); psh2 = *reinterpret_cast<const float4*>(b + 4); }
   }
   const float plo = (p.P.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
   {
     const float* c = (QTR && qs.scale) ? qs.scale + (qvalid ? qcl : 0) : g_wg_ident_scale;
     const float* d = (QTR && qs.scale) ? qs.shift + (qvalid ? qcl : 0) : g_wg_ident_shift;
     qsc = *reinterpret_cast<const float4*>(c); qsh = *reinterpret_cast<const float4*>(d);
-    if (S16) {
-      qsc2 = (QTR && qs.scale) ? *reinterpret_cast<const float4*>(c + 4) : qsc;
-      qsh2 = (QTR && qs.scale) ? *reinterpret_cast<const float4*>(d + 4) : qsh;
-    }
+    if (S16) { qsc2 = *reinterpret_cast<const float4*>(c + 4); qsh2 = *reinterpret_cast<const float4*>(d + 4); }
   }
   const float qlo = (qs.act == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
 

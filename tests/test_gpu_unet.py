@@ -326,16 +326,24 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
 
     p16, r16 = oracle(_bf16_rule)
     p32, r32 = oracle(None)
+    # Own tolerance of the bf16 mode, stated relative to what bf16 itself does to this network: d_ref = distance of the
+    # bf16 oracle (same operand AND storage rounding points) from the fp32 oracle, relative L2.  The HIP path must be as
+    # close to fp32 as its model (<= 1.25 d_ref), clearly closer to the model than to fp32 (<= 0.8 d_ref: what remains
+    # is operands whose last fp32 bits differ rounding to the other bf16 neighbour, and the materialised activation of
+    # mish / elu, which the oracle does not store), and really bf16 (>= 0.4 d_ref).
     for o, a, b in zip(outs, r16, r32):
-        assert rel_err(o.detach().cpu(), a.detach()) < 5e-3
-        assert 1e-4 < rel_err(o.detach().cpu(), b.detach()) < 3e-2        # really bf16, and a sane bf16
+        d_ref = _l2_rel(a.detach(), b.detach())
+        d_model, d_fp32 = _l2_rel(o.detach().cpu(), a.detach()), _l2_rel(o.detach().cpu(), b.detach())
+        print(f"output: d_ref {d_ref:.2e}, HIP vs bf16 oracle {d_model:.2e}, HIP vs fp32 {d_fp32:.2e}")
+        assert 1e-4 < d_ref < 5e-2
+        assert 0.4 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 0.8 * d_ref
     floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
     for k, p in net.named_parameters():
         if p32[k].grad.abs().max().item() <= floor:
             continue
         noise = _l2_rel(p16[k].grad, p32[k].grad)                          # what bf16 rounding itself does to this gradient
-        assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(2e-2, noise), k
-        assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(4e-2, 2 * noise), k
+        assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(2e-2, 1.25 * noise), k
+        assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(2e-2, 0.8 * noise), k
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
