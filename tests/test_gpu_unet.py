@@ -308,7 +308,9 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
             stored_bf16 = tr.nodes[0].z.dtype == torch.bfloat16
     finally:
         engine.set_precision("fp32")
-    assert stored_bf16          # these networks have bf16 kernels for every launch: activations are stored as bf16
+    # 64 px inputs: every launch has a bf16 kernel -> activations / gradients are STORED as bf16; the 48 px case falls back
+    # to fp32 tensors (operand rounding only).  The oracle models whichever the engine chose.
+    assert stored_bf16 == (size == 64)
 
     def oracle(rule):
         unet_ref.BF16_RULE = rule
