@@ -345,8 +345,8 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
         if p32[k].grad.abs().max().item() <= floor:
             continue
         noise = _l2_rel(p16[k].grad, p32[k].grad)                          # what bf16 rounding itself does to this gradient
-        assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(3e-2, 1.25 * noise), k     # floor: a few bf16 roundings (2^-9 each)
-        assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(3e-2, 1.25 * noise), k
+        assert _l2_rel(p.grad.cpu(), p32[k].grad) < max(3e-2, 1.5 * noise), k      # floor: a few bf16 roundings (2^-9 each)
+        assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(3e-2, 1.5 * noise), k
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
