@@ -454,12 +454,22 @@ def main():
         return rehearse(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  MSEG_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N-rank path (ranks share the visible
+    # GPUs round-robin, collectives go through gloo) — RCCL itself needs one GPU per rank
+    backend = os.environ.get("MSEG_BENCH_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ngpu:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU ({ngpu} visible); RCCL needs one GPU per rank")
+    dev_index = local_rank % max(ngpu, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from microbeseg_amd import engine
     out, net = train_metric(args, dev, world, rank, timing=not args.no_kernel_timing)
