@@ -148,69 +148,95 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
     }
 #pragma unroll
     for (int a = 0; a < Cfg::MB; ++a) {
-      // Affine row addressing: the 32 rows of one MFMA tile are consecutive GEMM rows, so when they lie on one image
-      // row the destination offset is base + row * step and the per-element divisions (costly VALU work that the
-      // short-K layers cannot hide) disappear.  Wave-uniform choice; the general decode below stays as the fallback.
+      // Row addressing.  The 32 rows of one MFMA tile are consecutive GEMM rows; the destination element of row `row` is
+      // tbase + rel(row), with everything that needs a division decoded ONCE per tile (wave-uniform) and only adds /
+      // compares per row — per-element divisions are VALU work the short-K layers (ConvTranspose: K = Cin) cannot hide:
+      //   mode 0  affine: rel = row * step  (one image-row segment; plain linear order; 32 | row length of the scatter /
+      //           parity forms)
+      //   mode 1  halo kernel with pixel tiles narrower than 32: shifts and masks
+      //   mode 2  scatter (ConvTranspose) over rows that are no multiple of 32: column wraps by compare
+      //   mode 3  parity order (stride-2 data gradient) likewise, inside one parity class
+      //   mode 4  tile straddling two parity classes (generic kernel only): full decode per element
       const int mb = m0 + wm * Cfg::TM + a * 32;
-      bool affine = false;
-      size_t base = 0;
-      int step = 0;
+      const int rows_left = (tw_log2 >= 0) ? 32 : M - mb;         // halo tiles never straddle the end of M
       bool tile_ok = mb < M;
+      int mode = 0, step = 0;
+      size_t tbase = 0;
+      int b_img = 0, b_y = 0, b_x = 0, cls = 0;                  // decoded first row of the tile (modes 2, 3)
       if (tw_log2 >= 0) {
-        if (tw_log2 >= 5) {       // halo kernel, pixel tile at least 32 wide: the MFMA tile is one image-row segment
-          const int i = wm * Cfg::TM + a * 32;
-          const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
-          tile_ok = oy < e_Ho;
-          base = ((size_t)(img2 * e_Ho + oy) * e_Wo + ox) * ld + noff;
-          step = ld;
-          affine = true;
-        }
+        const int i = wm * Cfg::TM + a * 32;
+        const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
+        tile_ok = oy < e_Ho;
+        tbase = ((size_t)(img2 * e_Ho + oy) * e_Wo + ox) * ld + noff;
+        step = ld;
+        mode = tw_log2 >= 5 ? 0 : 1;
       } else if (e_epi == MSEG_EPI_SCATTER2X2) {
-        if ((e_Wo & 31) == 0 && tile_ok) {
-          const int img = mb / (e_Ho * e_Wo);
-          const int rem = mb - img * (e_Ho * e_Wo);
-          const int oy = rem / e_Wo, ox = rem - oy * e_Wo;
-          base = (((size_t)img * (2 * e_Ho) + 2 * oy + sa) * (2 * e_Wo) + 2 * ox + sb) * e_Cq + noff;
+        if (tile_ok) {
+          b_img = mb / (e_Ho * e_Wo);
+          const int rem = mb - b_img * (e_Ho * e_Wo);
+          b_y = rem / e_Wo; b_x = rem - b_y * e_Wo;
+          tbase = (((size_t)b_img * (2 * e_Ho) + 2 * b_y + sa) * (2 * e_Wo) + 2 * b_x + sb) * e_Cq + noff;
           step = 2 * e_Cq;
-          affine = true;
+          mode = (e_Wo & 31) == 0 ? 0 : 2;
         }
       } else if (e_morder == MSEG_MORDER_PARITY) {
-        if (((e_Wo >> 1) & 31) == 0 && tile_ok) {
-          const RowInfo ri = decode_row(*pe, mb, M);
-          base = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
+        if (tile_ok) {
+          const int Hh = e_Ho >> 1, Wh = e_Wo >> 1, per = (M >> 2);
+          cls = mb / per;
+          const int rem = mb - cls * per;
+          b_img = rem / (Hh * Wh);
+          const int r2 = rem - b_img * (Hh * Wh);
+          b_y = r2 / Wh; b_x = r2 - b_y * Wh;
+          tbase = (((size_t)b_img * e_Ho + 2 * b_y + (cls >> 1)) * e_Wo + 2 * b_x + (cls & 1)) * ld + noff;
           step = 2 * ld;
-          affine = true;
+          mode = (Wh & 31) == 0 ? 0 : (rem + 31 < per ? 3 : 4);
         }
       } else {
-        base = (size_t)mb * ld + noff;
+        tbase = (size_t)mb * ld + noff;
         step = ld;
-        affine = true;
       }
-      if (affine) {
+      if (!nvalid || !tile_ok) continue;
+      const unsigned BAD = 0xffffffffu;
+      auto rel = [&](int row) -> unsigned {                       // element offset of `row` relative to tbase, or BAD
+        if (row >= rows_left) return BAD;
+        if (mode == 0) return (unsigned)(row * step);
+        if (mode == 1) {
+          const int i0 = wm * Cfg::TM + a * 32, i = i0 + row;
+          const int dy = (i >> tw_log2) - (i0 >> tw_log2), dx = (i & ((1 << tw_log2) - 1)) - (i0 & ((1 << tw_log2) - 1));
+          if (oy0 + (i >> tw_log2) >= e_Ho) return BAD;
+          return (unsigned)((dy * e_Wo + dx) * ld);
+        }
+        // modes 2 / 3: walk `row` pixels to the right inside a (rows x W) grid of W = Wo (scatter) or Wo / 2 (parity)
+        const int Wg = mode == 2 ? e_Wo : (e_Wo >> 1), Hg = mode == 2 ? e_Ho : (e_Ho >> 1);
+        int x = b_x + row, y = b_y, img = b_img;
+        while (x >= Wg) { x -= Wg; ++y; }                         // <= 2 trips for rows of >= 16 pixels
+        while (y >= Hg) { y -= Hg; ++img; }
+        const long long d = mode == 2
+            ? ((((long long)(img - b_img) * (2 * e_Ho) + 2 * (y - b_y)) * (2 * e_Wo)) + 2 * (x - b_x)) * e_Cq
+            : (((long long)(img - b_img) * e_Ho + 2 * (y - b_y)) * e_Wo + 2 * (x - b_x)) * ld;
+        return (unsigned)d;                                        // a 32-row tile spans a few image rows: fits 32 bits
+      };
+      if (mode != 4) {
         // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16
         // memory round trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
-        if (!nvalid || !tile_ok) continue;
-        const int rows_left = (tw_log2 >= 0) ? 32 : M - mb;      // halo tiles never straddle the end of M
-        float old[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = 0.f;
         if (e_d16) {
           // bf16 destination: a lane holds ONE channel of 16 rows, i.e. 2-byte stores.  Lanes 2k / 2k+1 (channels n, n+1;
           // bf16 storage has even channel counts) swap half of their values through a DPP quad permute, so that the even
           // lane stores the channel PAIR of the even accumulator rows and the odd lane that of the odd rows: 8 dword
           // stores (and 8 dword read-modify-write loads) per lane instead of 16 short ones.
           const bool odd = li & 1;
-          __bf16* const d = reinterpret_cast<__bf16*>(dst) + (base - (odd ? 1 : 0));      // first channel of the pair
-          unsigned oldw[8];
+          __bf16* const d = reinterpret_cast<__bf16*>(dst) + (tbase - (odd ? 1 : 0));     // first channel of the pair
+          unsigned oldw[8], ro[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) oldw[q] = 0u;
+          for (int q = 0; q < 8; ++q) {
+            const int r = 2 * q + (odd ? 1 : 0);
+            ro[q] = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
+            oldw[q] = 0u;
+          }
           if (accf) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int r = 2 * q + (odd ? 1 : 0);
-              const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (row < rows_left) oldw[q] = *reinterpret_cast<const unsigned*>(d + (unsigned)(row * step));
-            }
+            for (int q = 0; q < 8; ++q)
+              if (ro[q] != BAD) oldw[q] = *reinterpret_cast<const unsigned*>(d + ro[q]);
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -219,49 +245,34 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
             const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
             const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
             const float lo = (odd ? got : keep) + bf16_lo(oldw[q]), hi = (odd ? keep : got) + bf16_hi(oldw[q]);
-            const int r = 2 * q + (odd ? 1 : 0);
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < rows_left) *reinterpret_cast<unsigned*>(d + (unsigned)(row * step)) = pack_bf16x2(lo, hi);
+            if (ro[q] != BAD) *reinterpret_cast<unsigned*>(d + ro[q]) = pack_bf16x2(lo, hi);
           }
           continue;
         }
-        float* const d = dst + base;
+        float* const d = dst + tbase;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = 0.f;
         if (accf) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < rows_left) old[r] = d[(unsigned)(row * step)];
+            const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
+            if (o != BAD) old[r] = d[o];
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < rows_left) d[(unsigned)(row * step)] = acc[a][b][r] + bias + old[r];
+          const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
+          if (o != BAD) d[o] = acc[a][b][r] + bias + old[r];
         }
         continue;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        int m = mb + row;
-        if (tw_log2 >= 0) {   // 2-D pixel tile of the halo kernel: rows below the image are dropped
-          const int i = wm * Cfg::TM + a * 32 + row;
-          const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
-          m = oy < e_Ho ? (img2 * e_Ho + oy) * e_Wo + ox : M;
-        }
-        if (!nvalid || m >= M) continue;
-        size_t off;
-        if (e_epi == MSEG_EPI_SCATTER2X2) {
-          const int img = m / (e_Ho * e_Wo);
-          const int rem = m - img * (e_Ho * e_Wo);
-          const int oy = rem / e_Wo, ox = rem - oy * e_Wo;
-          off = (((size_t)img * (2 * e_Ho) + 2 * oy + sa) * (2 * e_Wo) + 2 * ox + sb) * e_Cq + noff;
-        } else if (e_morder == MSEG_MORDER_PARITY) {
-          const RowInfo ri = decode_row(*pe, m, M);
-          off = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
-        } else {
-          off = (size_t)m * ld + noff;
-        }
+      for (int r = 0; r < 16; ++r) {                              // mode 4: parity tile across two classes
+        const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= M) continue;
+        const RowInfo ri = decode_row(*pe, m, M);
+        const size_t off = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
         float v = acc[a][b][r] + bias;
         if (e_d16) {
           __bf16* const d = reinterpret_cast<__bf16*>(dst);
