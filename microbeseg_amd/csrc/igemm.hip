@@ -197,16 +197,18 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
       }
       if (!nvalid || !tile_ok) continue;
       const unsigned BAD = 0xffffffffu;
-      auto rel = [&](int row) -> unsigned {                       // element offset of `row` relative to tbase, or BAD
+      // element offset of `row` relative to tbase, or BAD — one closure per mode, selected by a wave-uniform branch
+      // OUTSIDE the row loops (a mode switch inside them is if-converted into selects that every row pays for)
+      auto rel_affine = [&](int row) -> unsigned { return row < rows_left ? (unsigned)(row * step) : BAD; };
+      auto rel_narrow = [&](int row) -> unsigned {
+        const int i0 = wm * Cfg::TM + a * 32, i = i0 + row;
+        const int dy = (i >> tw_log2) - (i0 >> tw_log2), dx = (i & ((1 << tw_log2) - 1)) - (i0 & ((1 << tw_log2) - 1));
+        if (oy0 + (i >> tw_log2) >= e_Ho) return BAD;
+        return (unsigned)((dy * e_Wo + dx) * ld);
+      };
+      // modes 2 / 3: walk `row` pixels to the right inside a (rows x W) grid of W = Wo (scatter) or Wo / 2 (parity)
+      auto rel_walk = [&](int row) -> unsigned {
         if (row >= rows_left) return BAD;
-        if (mode == 0) return (unsigned)(row * step);
-        if (mode == 1) {
-          const int i0 = wm * Cfg::TM + a * 32, i = i0 + row;
-          const int dy = (i >> tw_log2) - (i0 >> tw_log2), dx = (i & ((1 << tw_log2) - 1)) - (i0 & ((1 << tw_log2) - 1));
-          if (oy0 + (i >> tw_log2) >= e_Ho) return BAD;
-          return (unsigned)((dy * e_Wo + dx) * ld);
-        }
-        // modes 2 / 3: walk `row` pixels to the right inside a (rows x W) grid of W = Wo (scatter) or Wo / 2 (parity)
         const int Wg = mode == 2 ? e_Wo : (e_Wo >> 1), Hg = mode == 2 ? e_Ho : (e_Ho >> 1);
         int x = b_x + row, y = b_y, img = b_img;
         while (x >= Wg) { x -= Wg; ++y; }                         // <= 2 trips for rows of >= 16 pixels
@@ -216,9 +218,9 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
             : (((long long)(img - b_img) * e_Ho + 2 * (y - b_y)) * e_Wo + 2 * (x - b_x)) * ld;
         return (unsigned)d;                                        // a 32-row tile spans a few image rows: fits 32 bits
       };
-      if (mode != 4) {
-        // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16
-        // memory round trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
+      // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16 memory round
+      // trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
+      auto emit = [&](auto rel) {
         if (e_d16) {
           // bf16 destination: a lane holds ONE channel of 16 rows, i.e. 2-byte stores.  Lanes 2k / 2k+1 (channels n, n+1;
           // bf16 storage has even channel counts) swap half of their values through a DPP quad permute, so that the even
@@ -247,7 +249,7 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
             const float lo = (odd ? got : keep) + bf16_lo(oldw[q]), hi = (odd ? keep : got) + bf16_hi(oldw[q]);
             if (ro[q] != BAD) *reinterpret_cast<unsigned*>(d + ro[q]) = pack_bf16x2(lo, hi);
           }
-          continue;
+          return;
         }
         float* const d = dst + tbase;
         float old[16];
@@ -265,8 +267,10 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
           const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
           if (o != BAD) d[o] = acc[a][b][r] + bias + old[r];
         }
-        continue;
-      }
+      };
+      if (mode == 0) { emit(rel_affine); continue; }
+      if (mode == 1) { emit(rel_narrow); continue; }
+      if (mode != 4) { emit(rel_walk); continue; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {                              // mode 4: parity tile across two classes
         const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
