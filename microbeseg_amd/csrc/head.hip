@@ -5,46 +5,81 @@
 
 #define HEAD_MAXCO 4
 
+// A group of `lpp` lanes owns a pixel: every lane loads 16 bytes of it (4 fp32 / 8 bf16 channels per trip), multiplies by the
+// Co weight rows and the group reduces by shuffles.  U pixels are in flight per group (all loads issued before the first
+// use): with one load per trip the pass was latency-bound at 0.6 TB/s.
+template <bool S16>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const MsegSrc s, int N, int HW, const float* __restrict__ w,
                                                        const float* __restrict__ b, int Co, int lpp,
                                                        float* __restrict__ out) {
-  const int C4 = s.C >> 2;
+  constexpr int V = S16 ? 8 : 4, U = 4;
+  const int CV = s.C / V;
   const long long total = (long long)N * HW;
   const int sub = threadIdx.x % lpp;
-  const long long ppb = blockDim.x / lpp;  // pixels per block iteration
-  for (long long base = (long long)blockIdx.x * ppb; base < total; base += (long long)gridDim.x * ppb) {
+  const long long ppb = blockDim.x / lpp;  // pixels per block and slot
+  for (long long base = (long long)blockIdx.x * ppb * U; base < total; base += (long long)gridDim.x * ppb * U) {
     // all lanes of a wave stay in the loop together (shuffles below); out-of-range pixels contribute 0
-    const long long pix = base + threadIdx.x / lpp;
-    const bool valid = pix < total;
-    const int n = valid ? (int)(pix / HW) : 0;
-    float acc[HEAD_MAXCO] = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      for (int c4 = sub; c4 < C4; c4 += lpp) {
-        float4 v = src_load4(s, (size_t)pix * s.C + c4 * 4);
-        v = src_transform4(v, s, n, c4 * 4);
+    float acc[U][HEAD_MAXCO];
 #pragma unroll
-        for (int co = 0; co < HEAD_MAXCO; ++co) {
-          if (co < Co) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)co * s.C + c4 * 4);
-            acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
-          }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int co = 0; co < HEAD_MAXCO; ++co) acc[u][co] = 0.f;
+    for (int cv = sub; cv < CV; cv += lpp) {
+      uint4 raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long pix = base + u * ppb + threadIdx.x / lpp;
+        const size_t e = (size_t)(pix < total ? pix : 0) * s.C + cv * V;
+        raw[u] = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(s.ptr) + e)
+                     : *reinterpret_cast<const uint4*>(s.ptr + e);
+      }
+      float4 wv[HEAD_MAXCO][V / 4];
+#pragma unroll
+      for (int co = 0; co < HEAD_MAXCO; ++co)
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h)
+          wv[co][h] = co < Co ? *reinterpret_cast<const float4*>(w + (size_t)co * s.C + cv * V + 4 * h)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long pix = base + u * ppb + threadIdx.x / lpp;
+        if (pix >= total) continue;
+        const int n = (int)(pix / HW);
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h) {
+          float4 v;
+          if (S16) v = bf16x4_to_f32(h == 0 ? make_uint2(raw[u].x, raw[u].y) : make_uint2(raw[u].z, raw[u].w));
+          else v = make_float4(__uint_as_float(raw[u].x), __uint_as_float(raw[u].y), __uint_as_float(raw[u].z),
+                               __uint_as_float(raw[u].w));
+          v = src_transform4(v, s, n, cv * V + 4 * h);
+#pragma unroll
+          for (int co = 0; co < HEAD_MAXCO; ++co)
+            if (co < Co) acc[u][co] += v.x * wv[co][h].x + v.y * wv[co][h].y + v.z * wv[co][h].z + v.w * wv[co][h].w;
         }
       }
     }
     for (int o = lpp >> 1; o > 0; o >>= 1) {
 #pragma unroll
-      for (int co = 0; co < HEAD_MAXCO; ++co) acc[co] += __shfl_xor(acc[co], o, 64);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int co = 0; co < HEAD_MAXCO; ++co) acc[u][co] += __shfl_xor(acc[u][co], o, 64);
     }
-    if (valid && sub == 0) {
-      const int p = (int)(pix - (long long)n * HW);
-      for (int co = 0; co < Co; ++co) out[((size_t)n * Co + co) * HW + p] = acc[co] + (b ? b[co] : 0.f);
+    if (sub == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long pix = base + u * ppb + threadIdx.x / lpp;
+        if (pix >= total) continue;
+        const int n = (int)(pix / HW);
+        const int p = (int)(pix - (long long)n * HW);
+        for (int co = 0; co < Co; ++co) out[((size_t)n * Co + co) * HW + p] = acc[u][co] + (b ? b[co] : 0.f);
+      }
     }
   }
 }
 
-static int head_lpp(int C4) {
+static int head_lpp(int CV) {
   int l = 1;
-  while (l * 2 <= C4 && l * 2 <= 16) l *= 2;
+  while (l * 2 <= CV && l * 2 <= 16) l *= 2;
   return l;
 }
 
@@ -52,13 +87,19 @@ extern "C" int mseg_head_fwd(const MsegSrc* src, int N, int HW, const float* w, 
                              float* out_nchw, void* stream) {
   if (!src || !src->ptr || !w || !out_nchw || N <= 0 || HW <= 0 || Co <= 0 || Co > HEAD_MAXCO) return MSEG_EINVAL;
   if (src->C <= 0 || (src->C & 3)) return MSEG_EINVAL;
-  const int lpp = head_lpp(src->C >> 2);
+  const bool s16 = src->dtype == MSEG_ST_BF16;
+  if (s16 && (src->C & 7)) return MSEG_EINVAL;
+  const int lpp = head_lpp(src->C / (s16 ? 8 : 4));
   const long long total = (long long)N * HW;
-  const long long ppb = 256 / lpp;
+  const long long ppb = (256 / lpp) * 4;       // pixels per block and trip (U = 4 per group)
   long long blocks = (total + ppb - 1) / ppb;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *src, N, HW, w, b, Co,
-                     lpp, out_nchw);
+  if (s16)
+    hipLaunchKernelGGL((head_fwd_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *src, N, HW, w,
+                       b, Co, lpp, out_nchw);
+  else
+    hipLaunchKernelGGL((head_fwd_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *src, N, HW, w,
+                       b, Co, lpp, out_nchw);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -121,22 +162,39 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom
 #pragma unroll
       for (int co = 0; co < HEAD_MAXCO; ++co)
         wv[co] = co < g.Co ? *reinterpret_cast<const float4*>(w + (size_t)co * g.C + c) : make_float4(0, 0, 0, 0);
-      for (int r = row_begin + r0; r < row_end; r += rpi) {
-        const size_t off = ((size_t)n * g.HW + r) * g.C + c;
-        float4 yv = src_load4(s, off);
-        yv = src_transform4(yv, s, n, c);
-        float4 o = make_float4(0, 0, 0, 0);
+      constexpr int U = 4;                               // rows in flight per thread (loads issued before the first use)
+      for (int r = row_begin + r0; r < row_end; r += rpi * U) {
+        float4 yraw[U];
+        float gv[U][HEAD_MAXCO];
+        bool ok[U];
 #pragma unroll
-        for (int co = 0; co < HEAD_MAXCO; ++co) {
-          if (co < g.Co) {
-            const float gv = gout[((size_t)n * g.Co + co) * g.HW + r];
-            o.x += gv * wv[co].x; o.y += gv * wv[co].y; o.z += gv * wv[co].z; o.w += gv * wv[co].w;
-            dw[co][0] += (double)gv * yv.x; dw[co][1] += (double)gv * yv.y;
-            dw[co][2] += (double)gv * yv.z; dw[co][3] += (double)gv * yv.w;
-            if (c4 == 0) dbs[co] += gv;
-          }
+        for (int u = 0; u < U; ++u) {
+          const int ru = r + u * rpi;
+          ok[u] = ru < row_end;
+          const int rr = ok[u] ? ru : r;
+          yraw[u] = src_load4(s, ((size_t)n * g.HW + rr) * g.C + c);
+#pragma unroll
+          for (int co = 0; co < HEAD_MAXCO; ++co)
+            gv[u][co] = co < g.Co ? gout[((size_t)n * g.Co + co) * g.HW + rr] : 0.f;
         }
-        st_f4_rt(gy, off, o, gy_dtype);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
+          const float4 yv = src_transform4(yraw[u], s, n, c);
+          float4 o = make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int co = 0; co < HEAD_MAXCO; ++co) {
+            if (co < g.Co) {
+              const float gvc = gv[u][co];
+              o.x += gvc * wv[co].x; o.y += gvc * wv[co].y; o.z += gvc * wv[co].z; o.w += gvc * wv[co].w;
+              dw[co][0] += (double)gvc * yv.x; dw[co][1] += (double)gvc * yv.y;
+              dw[co][2] += (double)gvc * yv.z; dw[co][3] += (double)gvc * yv.w;
+              if (c4 == 0) dbs[co] += gvc;
+            }
+          }
+          st_f4_rt(gy, off, o, gy_dtype);
+        }
       }
     }
     for (int co = 0; co < g.Co; ++co) {
