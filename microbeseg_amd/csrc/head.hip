@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const MsegSrc s, HeadGeom
 #pragma unroll
       for (int co = 0; co < HEAD_MAXCO; ++co)
         wv[co] = co < g.Co ? *reinterpret_cast<const float4*>(w + (size_t)co * g.C + c) : make_float4(0, 0, 0, 0);
-      constexpr int U = 4;                               // rows in flight per thread (loads issued before the first use)
+      constexpr int U = 1;                               // measured: U = 4 spills the fp64 sums (349 -> 514 us); kept general
       for (int r = row_begin + r0; r < row_end; r += rpi * U) {
         float4 yraw[U];
         float gv[U][HEAD_MAXCO];
