@@ -141,10 +141,15 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
           zv[u].get(zf);
           if ((MODE == 1 || MODE == 2) && aio) av[u].get(a4);
           else {
+            if (S16 && act != MSEG_ACT_NONE && act != MSEG_ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < V; j += 4) {         // act_fwd4: the cheap activations take a wave-uniform fast path
-              const float4 t = act_fwd4(make_float4(zf[j], zf[j + 1], zf[j + 2], zf[j + 3]), act);
-              a4[j] = t.x; a4[j + 1] = t.y; a4[j + 2] = t.z; a4[j + 3] = t.w;
+              for (int j = 0; j < V; ++j) a4[j] = act_fwd_fast(zf[j], act);
+            } else {
+#pragma unroll
+              for (int j = 0; j < V; j += 4) {       // act_fwd4: the cheap activations take a wave-uniform fast path
+                const float4 t = act_fwd4(make_float4(zf[j], zf[j + 1], zf[j + 2], zf[j + 3]), act);
+                a4[j] = t.x; a4[j + 1] = t.y; a4[j + 2] = t.z; a4[j + 3] = t.w;
+              }
             }
           }
           if ((MODE == 0 || MODE == 3) && aio)
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
             } else {
               float d[V];
 #pragma unroll
-              for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * act_bwd(zf[j], act);
+              for (int j = 0; j < V; ++j)
+                d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * (S16 ? act_bwd_fast(zf[j], act) : act_bwd(zf[j], act));
               NormVec<S16>::put(dz, off, d);      // d now holds dz as stored
 #pragma unroll
               for (int j = 0; j < V; ++j) s0[j] += d[j];

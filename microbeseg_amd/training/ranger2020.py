@@ -93,6 +93,7 @@ class Ranger(Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        fused = []
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             for p in group['params']:
@@ -103,6 +104,7 @@ class Ranger(Optimizer):
                 state = self.state[p]
                 if p.is_cuda and p.dtype == torch.float32 and group['weight_decay'] == 0 and self.gc_loc:
                     self._fused_step(p, state, group, beta1, beta2)
+                    fused.append(p)
                     continue
                 grad = p.grad.detach().float().clone()
                 if len(state) == 0:
@@ -130,4 +132,7 @@ class Ranger(Optimizer):
                     slow = state['slow_buffer']
                     slow.add_(p - slow, alpha=self.alpha)
                     p.copy_(slow)
+        if fused:            # all packed convolution operands of the updated weights in ONE launch (engine.repack_all)
+            from .. import engine
+            engine.repack_all(fused)
         return None
