@@ -516,6 +516,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     if bf16:
         name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
             "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")
+        name = name[:-1] + (", true>" if srcs[0].dtype == ST_BF16 else ", false>")      # S16: bf16-stored operands
     e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
@@ -572,7 +573,7 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
     name = _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride)
     if bf16:
-        name = bf16
+        name = bf16[:-1] + (", true>" if P.dtype == ST_BF16 else ", false>")
     e0, e1 = _timer.bracket(name, flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
     e0.record()

@@ -40,10 +40,11 @@ def test_pmc_profile_is_selected_by_workload():
     import argparse
     a = argparse.Namespace(batch=32, size=256, arch="DU", act="relu", norm="bn", filters=[64, 1024], optimizer="adam",
                            precision="fp32")
-    got = bench.pmc_traffic("wgrad_halo_kernel<5, 1>", a)
+    got = bench.pmc_traffic("wgrad_halo9_kernel<3, 1>", a)
     assert got["traffic"] and got["traffic"] > 1e8 and "bf16" not in got["traffic_source"]
+    assert got["traffic_source"] >= "profiles/r02b"      # the newest profile of the workload wins
     a.precision, a.size = "bf16", 320
-    got = bench.pmc_traffic("wgrad_halo_bf16_kernel<3, 1, 1, 3, 0>", a)
+    got = bench.pmc_traffic("igemm_halo_bf16w4_kernel<0, true>", a)      # bf16-stored operands (S16 form)
     assert got["traffic"] and "bf16_320" in got["traffic_source"]
     a.size = 512                               # no profile of that workload: say so instead of borrowing another one's
-    assert bench.pmc_traffic("wgrad_halo_bf16_kernel<3, 1, 1, 3, 0>", a) == {"traffic": None, "traffic_source": "none"}
+    assert bench.pmc_traffic("igemm_halo_bf16w4_kernel<0, true>", a) == {"traffic": None, "traffic_source": "none"}
