@@ -374,8 +374,11 @@ def train_metric(args, dev, world, rank, timing=True):
 
     for i in range(warmup):
         step(i)
+    # bf16 steps are short enough (32-50 ms) that the ~1300 event records of the kernel bracketing make them host-bound:
+    # there `value` comes from K un-bracketed steps and the kernel table / roofline from K more, bracketed steps
+    two_pass = timing and args.precision == "bf16"
     prof = engine.KernelTimer() if timing else None
-    engine.set_kernel_timer(prof)
+    engine.set_kernel_timer(None if two_pass else prof)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -383,6 +386,16 @@ def train_metric(args, dev, world, rank, timing=True):
     fence()
     dt = time.perf_counter() - t0
     engine.set_kernel_timer(None)
+    dt_bracketed = None
+    if two_pass:
+        engine.set_kernel_timer(prof)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        dt_bracketed = time.perf_counter() - t0
+        engine.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,6 +434,9 @@ def train_metric(args, dev, world, rank, timing=True):
             out["frac_of_fp32_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_FP32_MFMA_TFLOPS, 4)
         else:
             out["frac_of_bf16_mfma_peak"] = round(value / world * train_tflop_per_crop / PEAK_BF16_MFMA_TFLOPS, 4)
+    if dt_bracketed is not None:
+        out["kernel_timing"] = "separate bracketed pass of %d steps (%.3f ms/step with HIP-event bracketing)" % (
+            args.steps, 1e3 * dt_bracketed / args.steps)
     if prof is not None:
         kernels = prof.summary()
         if kernels:
@@ -486,20 +502,9 @@ def main():
         a2 = copy.copy(args)
         a2.precision, a2.size, a2.graph = "bf16", 320, False
         a2.steps, a2.warmup = max(args.steps, 10), max(args.warmup, 3)
-        # at ~58 ms per step the ~1300 event records of the kernel bracketing make the step host-bound, so this block takes
-        # its `value` from a run WITHOUT bracketing and the kernel table / roofline from a second, bracketed run
-        blk, net2 = train_metric(a2, dev, 1, 0, timing=False)
+        blk, net2 = train_metric(a2, dev, 1, 0, timing=not args.no_kernel_timing)   # two-pass timing, see train_metric
         del net2
         torch.cuda.empty_cache()
-        if not args.no_kernel_timing:
-            timed, net2 = train_metric(a2, dev, 1, 0, timing=True)
-            del net2
-            torch.cuda.empty_cache()
-            blk["kernel_timing"] = "separate bracketed pass of %d steps (%.3f ms/step with HIP-event bracketing)" % (
-                a2.steps, timed["ms_per_step"])
-            for key in ("roofline", "kernels"):
-                if key in timed:
-                    blk[key] = timed[key]
         engine.set_precision(args.precision)
         out["bf16_320"] = blk
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
