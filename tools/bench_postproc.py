@@ -25,6 +25,15 @@ t0 = time.time(); want = R.distance_postprocessing(border[..., None], cell[..., 
 print(f"CPU oracle (1 thread) {dt*1e3:.0f} ms/frame  {H*W/dt/1e6:.2f} Mpx/s")
 got = labels.cpu().numpy().view(np.uint16)
 print("bit-exact:", bool(np.array_equal(got, want)), "mismatch px", int((got != want).sum()))
+from scipy import ndimage as ndi
+comp, ncomp = ndi.label(got != 0)                       # 4-connected mask components = independent floods
+areas = np.bincount(comp.ravel())[1:]
+sl = ndi.find_objects(comp)
+big = np.argsort(areas)[::-1][:5]
+print(f"mask components {ncomp}: area mean {areas.mean():.0f} max {areas.max()}  largest bboxes "
+      + ", ".join(f"{areas[i]}px in {sl[i][0].stop - sl[i][0].start}x{sl[i][1].stop - sl[i][1].start}" for i in big))
+if len(sys.argv) > 3 and sys.argv[3] == "pp-only":
+    sys.exit(0)
 
 # ---- evaluation: 4 x 2 threshold sweep (one call, shared smoothing) vs 8 separate calls; AJI+ scoring of one pair ----
 from microbeseg_amd.evaluation import stats_utils as su
