@@ -257,6 +257,12 @@ int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, 
  * reference gets for (H,W,1) inputs.  status_dev[0] receives flags (bit0: exact
  * serial path was used).                                                                                        */
 size_t mseg_postproc_workspace_bytes(int H, int W);
+/* Test / tuning hook of the per-component watershed flood (one wavefront per mask component, csrc/postproc.hip):
+ * heap_rows = rows of the wave's queue kept in LDS (1..16, the rest spills to the workspace); tile_small_px /
+ * tile_large_px = bounding-box capacities (pixels incl. a 1 px rim) of the two LDS-staged launches (<= 8192 / <= 30720;
+ * 0 = probe global memory instead).  Negative values restore the defaults.  Results never depend on these values; the
+ * tests use them to drive the spill and global-probe paths.  Process-wide. */
+int mseg_postproc_tuning(int heap_rows, int tile_small_px, int tile_large_px);
 int mseg_distance_postprocess(const float* border, const float* cell, int H, int W, float th_cell, float th_seed,
                               int col_major_ids, uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev,
                               void* ws, size_t ws_bytes, void* stream);

@@ -147,3 +147,34 @@ def test_boundary_postprocessing_matches_oracle_random(H, W, n, seed, pp):
     want = postproc_ref.boundary_postprocessing(probs)
     assert got.dtype == np.uint16 and np.array_equal(got, want)
     assert want.max() >= 3
+
+
+@pytest.mark.parametrize("rows,tile_s,tile_l", [(1, -1, -1), (16, 0, 0), (1, 0, 0), (2, 400, 2000), (16, 0, -1)])
+def test_component_flood_paths_agree(rows, tile_s, tile_l, pp):
+    """The per-component flood (one wavefront per mask component) keeps its queue in LDS with a spill into the workspace
+    and stages the component's bounding box in LDS, probing global memory for boxes beyond the tile.  mseg_postproc_tuning
+    shrinks the LDS shares so that small test frames drive the spill rows, the large-tile launch and the global-probe
+    path; labels must stay bit-identical to the oracle on tie-free and on quantised (tied) frames alike."""
+    from oracle import postproc_ref as R
+    from microbeseg_amd import _lib
+    from microbeseg_amd.utils import synth
+    lib = _lib.load()
+    assert lib.mseg_postproc_tuning(0, -1, -1) != 0 and lib.mseg_postproc_tuning(17, -1, -1) != 0
+    assert lib.mseg_postproc_tuning(rows, tile_s, tile_l) == 0
+    try:
+        for s, levels in enumerate((0, 0, 1 << 12, 1 << 9)):
+            rng = np.random.Generator(np.random.PCG64(4242 + s))
+            H, W = int(rng.integers(150, 260)), int(rng.integers(150, 260))
+            cell, border = synth.synth_prediction_maps(rng, H, W, int(rng.integers(80, 160)), rmin=5, rmax=13)
+            if levels:
+                cell = (np.round(cell * levels) / levels).astype(np.float32)
+            for th_cell, th_seed in ((0.10, 0.45), (0.02, 0.30)):      # the low cell threshold merges cells into big components
+                c, b = torch.from_numpy(cell).cuda(), torch.from_numpy(border).cuda()
+                labels, _, status = pp.distance_postprocessing_device(b, c, th_seed, th_cell, col_major_ids=True)
+                want = R.distance_postprocessing(border[..., None], cell[..., None], th_seed, th_cell)
+                got = labels.cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want), f"frame {s} th {th_cell}: {(got != want).sum()} px differ, status {int(status)}"
+                if not levels:
+                    assert int(status) & 1 == 0, "tie-free data must stay on the per-component flood"
+    finally:
+        assert lib.mseg_postproc_tuning(-1, -1, -1) == 0
