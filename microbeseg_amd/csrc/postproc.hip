@@ -25,7 +25,7 @@
 
 // counters (int32 slots in workspace)
 enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_CONST_M = 7,
-       C_CONST_Q = 12, C_WORK_S = 13, C_WORK_L = 14, C_COUNT = 16 };
+       C_CONST_Q = 12, C_WORK_S = 16, C_WORK_L = 18, C_COUNT = 20 };   // C_WORK_*: two slots each
 
 struct PPWs {
   float* tmp; float* cs;
@@ -204,14 +204,18 @@ __global__ void pp_seed_stats_kernel(const int32_t* __restrict__ L, int H, int W
                                      int32_t* __restrict__ counters) {
   const size_t n = (size_t)H * W;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int r = L[i];
-  if (r < 0) return;
-  atomicAdd(&area[r], 1);
-  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-  atomicMin(&ckey[r], col_major ? x * H + y : (int)i);
-  atomicAdd(&counters[C_TOTAL], 1);
-  if (r == (int)i) atomicAdd(&counters[C_NCOMP], 1);
+  const int r = i < n ? L[i] : -1;
+  if (r >= 0) {
+    atomicAdd(&area[r], 1);
+    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    atomicMin(&ckey[r], col_major ? x * H + y : (int)i);
+  }
+  // the two frame-wide counts: one atomic per wavefront instead of one per seed pixel
+  const unsigned long long seeds = __ballot(r >= 0), roots = __ballot(r >= 0 && r == (int)i);
+  if ((threadIdx.x & 63) == 0) {
+    if (seeds) atomicAdd(&counters[C_TOTAL], __popcll(seeds));
+    if (roots) atomicAdd(&counters[C_NCOMP], __popcll(roots));
+  }
 }
 
 __device__ __forceinline__ bool pp_keep(int area, const int32_t* counters, int distance_rule) {
@@ -559,217 +563,253 @@ __device__ __forceinline__ unsigned ppw_wave_min(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// One component.  LDS: the box is staged in s_tile and a queue entry names its pixel by tile coordinates (row << 16 | col);
+// otherwise entries carry the raster index and the probes go to global memory.  SPILL: queue rows >= rows_lds exist.
+template <bool LDS, bool SPILL>
+__device__ __forceinline__ int ppw_component(
+    unsigned long long* s_key, uint32_t* s_idx, int32_t* s_lab, uint32_t* s_tile, const float* __restrict__ img,
+    const uint8_t* __restrict__ mask, const int32_t* __restrict__ mlab, unsigned long long* __restrict__ gkey,
+    uint32_t* __restrict__ gidx, int32_t* __restrict__ glab, int32_t* out, int H, int W, int root, int y0, int x0, int th,
+    int tw, int rows_lds) {
+  const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const long long px = (long long)th * tw;
+  int taint = 0;
+  // column `lane` of the queue: rows < rows_lds in LDS, the rest in the component's global segment
+  int cnt = 0, mrow = 0;
+  unsigned long long mk = ~0ull;
+  auto q_key = [&](int r) { return (!SPILL || r < rows_lds) ? s_key[r * 64 + lane] : gkey[(r - rows_lds) * 64 + lane]; };
+  auto q_idx = [&](int r) { return (!SPILL || r < rows_lds) ? s_idx[r * 64 + lane] : gidx[(r - rows_lds) * 64 + lane]; };
+  auto q_lab = [&](int r) { return (!SPILL || r < rows_lds) ? s_lab[r * 64 + lane] : glab[(r - rows_lds) * 64 + lane]; };
+  auto q_set_at = [&](int r, int col, unsigned long long k, uint32_t ix, int lb) {
+    if (!SPILL || r < rows_lds) { s_key[r * 64 + col] = k; s_idx[r * 64 + col] = ix; s_lab[r * 64 + col] = lb; }
+    else { const int g = (r - rows_lds) * 64 + col; gkey[g] = k; gidx[g] = ix; glab[g] = lb; }
+  };
+  auto q_rescan = [&]() {
+    mk = ~0ull; mrow = 0;
+#pragma unroll 4
+    for (int r = 0; r < cnt; ++r) {
+      const unsigned long long k = q_key(r);
+      if (k < mk) { mk = k; mrow = r; }
+    }
+  };
+
+  // ---- stage the box, collect the initial markers (all with age 0) ----
+  int total = 0;
+  int ty = 0, tx = lane;                                  // tile coordinates of p = p0 + lane, kept without divisions
+  while (tx >= tw) { tx -= tw; ++ty; }
+  const int sy = 64 / tw, sx = 64 - sy * tw;              // 64 = sy * tw + sx
+  for (long long p0 = 0; p0 < px; p0 += 64) {
+    const long long p = p0 + lane;
+    bool is_marker = false;
+    unsigned long long k0 = 0; uint32_t j0 = 0; int l0 = 0;
+    if (p < px) {
+      uint32_t tv = PPW_SENT;
+      if (ty > 0 && ty < th - 1 && tx > 0 && tx < tw - 1) {
+        const uint32_t j = (uint32_t)(y0 - 1 + ty) * (uint32_t)W + (uint32_t)(x0 - 1 + tx);
+        if (mask[j]) {
+          const int m = out[j];                           // = markers[j] (pp_markers_kernel)
+          const float v = img[j];
+          if (m != 0) {
+            if (mlab[j] == root) { is_marker = true; k0 = pp_key(v, 0u); j0 = LDS ? ((uint32_t)ty << 16 | (uint32_t)tx) : j; l0 = m; }
+          } else {
+            tv = __float_as_uint(v);
+          }
+        }
+      }
+      if (LDS) s_tile[p] = tv;
+    }
+    const unsigned long long bal = __ballot(is_marker);
+    if (is_marker) {
+      const int slot = total + __popcll(bal & lt_mask);
+      q_set_at(slot >> 6, slot & 63, k0, j0, l0);
+    }
+    total += __popcll(bal);
+    ty += sy; tx += sx;
+    if (tx >= tw) { tx -= tw; ++ty; }
+  }
+  if (SPILL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // spilled rows were written by other lanes
+  __syncthreads();
+  if (SPILL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  cnt = total > lane ? (total - lane + 63) >> 6 : 0;
+  q_rescan();
+
+  // ---- flood ----
+  const int dy = lane == 0 ? -1 : (lane == 3 ? 1 : 0), dx = lane == 1 ? -1 : (lane == 2 ? 1 : 0);
+  const int dt = dy * tw + dx, dj = dy * W + dx;
+  const int jbase = (y0 - 1) * W + (x0 - 1);
+  unsigned age = 0u;
+  unsigned long long prev0_key = ~0ull;   // tracking state of pp_flood<true>, uniform over the wave
+  int prev0_label = 0, since_prev0 = 0;
+  bool prev0_tied = false, sticky = false, watch_diff = false;
+  uint32_t pushed_prev[4] = {PPW_SENT, PPW_SENT, PPW_SENT, PPW_SENT};
+  unsigned pushed_prev_val[4] = {0u, 0u, 0u, 0u};
+  unsigned prev_val = 0xffffffffu, watch_val = 0u;
+  while (total > 0) {
+    // pop: smallest (value, age) over the cached column minima
+    const unsigned hi = cnt > 0 ? (unsigned)(mk >> 32) : 0xffffffffu;
+    const unsigned mh = ppw_wave_min(hi);
+    const unsigned lo = (cnt > 0 && hi == mh) ? (unsigned)mk : 0xffffffffu;
+    const unsigned ml = ppw_wave_min(lo);
+    const unsigned long long k = ((unsigned long long)mh << 32) | ml;
+    const int winner = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cnt > 0 && mk == k)) - 1);
+    uint32_t e = 0; int lab = 0;
+    if (lane == winner) {
+      e = q_idx(mrow); lab = q_lab(mrow);
+      const int last = cnt - 1;
+      if (mrow != last) q_set_at(mrow, lane, q_key(last), q_idx(last), q_lab(last));
+      cnt = last;
+      q_rescan();
+    }
+    e = (uint32_t)__builtin_amdgcn_readlane((int)e, winner);
+    lab = __builtin_amdgcn_readlane(lab, winner);
+    --total;
+
+    bool tie = false, tie_diff = false, had_cascade = false;
+    {
+      const unsigned val = mh, a = ml;
+      if (sticky && val == prev_val) taint |= 16;                              // rule 3
+      if (watch_val && val < watch_val) {                                      // Y's cascade
+        if (watch_diff) taint |= 4;                                            // rule 2b
+        else sticky = true;                                                    // rule 3b
+      }
+      if (a == 0u) {
+        if (k == prev0_key) {
+          tie = true;
+          tie_diff = (lab != prev0_label);
+          if (prev0_tied) sticky = true;                                       // rule 3b (chain of ties)
+          had_cascade = since_prev0 > 0;
+          if (since_prev0 > 0) {
+            if (tie_diff) taint |= 2;                                          // rule 2a
+            else sticky = true;                                                // rule 3b
+          }
+          watch_val = val; watch_diff = tie_diff;
+        } else {
+          watch_val = 0u;
+        }
+        prev0_tied = tie;
+        prev0_key = k; prev0_label = lab; since_prev0 = 0;
+      } else {
+        ++since_prev0;
+      }
+      prev_val = val;
+    }
+
+    // neighbours in skimage's order up, left, right, down: lanes 0..3
+    bool push = false;
+    uint32_t jn = 0;                                       // the neighbour's name in this mode (tile coordinates / raster index)
+    unsigned long long nk = 0;
+    float v = 0.f;
+    if (lane < 4) {
+      bool valid;
+      if (LDS) {
+        const int ey = (int)(e >> 16), ex = (int)(e & 0xffffu);
+        const int t = ey * tw + ex + dt;
+        const uint32_t tv = s_tile[t];
+        jn = (uint32_t)(ey + dy) << 16 | (uint32_t)(ex + dx);
+        valid = true;                                      // a rim pixel is never in pushed_prev
+        push = tv != PPW_SENT;
+        v = __uint_as_float(tv);
+        if (push) { s_tile[t] = PPW_SENT; out[jbase + ey * W + ex + dj] = lab; }
+      } else {
+        const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+        valid = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+        jn = (uint32_t)((int)e + dj);
+        if (valid && mask[jn]) {
+          push = __hip_atomic_load(&out[jn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+          if (push) {
+            v = img[jn];
+            __hip_atomic_store(&out[jn], lab, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      if (!push && tie_diff && valid &&
+          (jn == pushed_prev[0] || jn == pushed_prev[1] || jn == pushed_prev[2] || jn == pushed_prev[3]))
+        taint |= 1;                                                            // rule 1
+    }
+    const unsigned pb = (unsigned)__ballot(push) & 0xfu;
+    if (push) nk = pp_key(v, age + 1u + (unsigned)__popc(pb & ((1u << lane) - 1u)));
+    age += (unsigned)__popc(pb);
+    uint32_t pushed_now[4] = {PPW_SENT, PPW_SENT, PPW_SENT, PPW_SENT};
+    unsigned pushed_now_val[4] = {0u, 0u, 0u, 0u};
+    bool first = true;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (!((pb >> sl) & 1u)) continue;                                        // uniform
+      const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nk >> 32), sl);
+      const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nk, sl);
+      const uint32_t js = (uint32_t)__builtin_amdgcn_readlane((int)jn, sl);
+      const unsigned long long ks = ((unsigned long long)khi << 32) | klo;
+      pushed_now[sl] = js; pushed_now_val[sl] = khi;
+      int t = winner;                                     // the column that just lost a row ...
+      if (!first) t = (int)(ppw_wave_min(((unsigned)cnt << 6) | (unsigned)lane) & 63u);   // ... else the shortest one
+      first = false;
+      if (lane == t) {
+        q_set_at(cnt, lane, ks, js, lab);
+        if (ks < mk) { mk = ks; mrow = cnt; }
+        ++cnt;
+      }
+      ++total;
+    }
+    if (ml == 0u) {
+      if (tie && !had_cascade) {                                               // rule 3a
+#pragma unroll
+        for (int pn = 0; pn < 4; ++pn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (pushed_now[pn] != PPW_SENT && pushed_prev[q] != PPW_SENT && pushed_now_val[pn] == pushed_prev_val[q]) {
+              if (tie_diff) taint |= 8; else sticky = true;
+            }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { pushed_prev[q] = pushed_now[q]; pushed_prev_val[q] = pushed_now_val[q]; }
+    }
+  }
+  __syncthreads();                                        // the next component reuses the tile
+  return taint;
+}
+
+#define PPW_BIG_AREA 512      // components at least this large are started first (the longest one bounds the launch)
+
 template <int TILE_PX>
 __global__ __launch_bounds__(64) void pp_flood_wave_kernel(
     const float* __restrict__ img, const uint8_t* __restrict__ mask, const int32_t* __restrict__ mlab,
-    const int32_t* __restrict__ clist, const int32_t* __restrict__ hoff, const int32_t* __restrict__ bymin,
-    const int32_t* __restrict__ bymax, const int32_t* __restrict__ bxmin, const int32_t* __restrict__ bxmax,
-    unsigned long long* __restrict__ hkey, uint32_t* __restrict__ hidx, int32_t* __restrict__ hlab,
-    int32_t* out, int H, int W, int32_t* __restrict__ counters, int work_slot, long long px_lo, long long px_hi,
-    int tile_px, int rows_lds) {
+    const int32_t* __restrict__ clist, const int32_t* __restrict__ hoff, const int32_t* __restrict__ carea,
+    const int32_t* __restrict__ bymin, const int32_t* __restrict__ bymax, const int32_t* __restrict__ bxmin,
+    const int32_t* __restrict__ bxmax, unsigned long long* __restrict__ hkey, uint32_t* __restrict__ hidx,
+    int32_t* __restrict__ hlab, int32_t* out, int H, int W, int32_t* __restrict__ counters, int work_slot,
+    long long px_lo, long long px_hi, int tile_px, int rows_lds) {
   __shared__ unsigned long long s_key[PPW_CAP];
   __shared__ uint32_t s_idx[PPW_CAP];
   __shared__ int32_t s_lab[PPW_CAP];
   __shared__ uint32_t s_tile[TILE_PX];
   if (counters[C_SERIAL]) return;                        // caller forces the exact serial path (boundary method)
   const int lane = threadIdx.x;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int ncomp = counters[C_NMCOMP];
   int taint = 0;
-  for (;;) {
-    int c = 0;
-    if (lane == 0) c = atomicAdd(&counters[work_slot], 1);
-    c = __builtin_amdgcn_readfirstlane(c);
-    if (c >= ncomp) break;
-    const int root = clist[c];
-    const int y0 = bymin[root], y1 = bymax[root], x0 = bxmin[root], x1 = bxmax[root];
-    const int th = y1 - y0 + 3, tw = x1 - x0 + 3;         // bounding box + 1 px rim
-    const long long px = (long long)th * tw;
-    if (px <= px_lo || px > px_hi) continue;              // the other launch's class
-    const bool lds = px <= (long long)tile_px;
-    unsigned long long* gkey = hkey + hoff[root];
-    uint32_t* gidx = hidx + hoff[root];
-    int32_t* glab = hlab + hoff[root];
-
-    // column `lane` of the queue: rows < rows_lds in LDS, the rest in the component's global segment
-    int cnt = 0, mrow = 0;
-    unsigned long long mk = ~0ull;
-    auto q_key = [&](int r) { return r < rows_lds ? s_key[r * 64 + lane] : gkey[(r - rows_lds) * 64 + lane]; };
-    auto q_idx = [&](int r) { return r < rows_lds ? s_idx[r * 64 + lane] : gidx[(r - rows_lds) * 64 + lane]; };
-    auto q_lab = [&](int r) { return r < rows_lds ? s_lab[r * 64 + lane] : glab[(r - rows_lds) * 64 + lane]; };
-    auto q_set_at = [&](int r, int col, unsigned long long k, uint32_t ix, int lb) {
-      if (r < rows_lds) { s_key[r * 64 + col] = k; s_idx[r * 64 + col] = ix; s_lab[r * 64 + col] = lb; }
-      else { const int g = (r - rows_lds) * 64 + col; gkey[g] = k; gidx[g] = ix; glab[g] = lb; }
-    };
-    auto q_rescan = [&]() {
-      mk = ~0ull; mrow = 0;
-#pragma unroll 4
-      for (int r = 0; r < cnt; ++r) {
-        const unsigned long long k = q_key(r);
-        if (k < mk) { mk = k; mrow = r; }
-      }
-    };
-
-    // ---- stage the box, collect the initial markers (all with age 0) ----
-    int total = 0;
-    for (long long p0 = 0; p0 < px; p0 += 64) {
-      const long long p = p0 + lane;
-      bool is_marker = false;
-      unsigned long long k0 = 0; uint32_t j0 = 0; int l0 = 0;
-      if (p < px) {
-        const int ty = (int)(p / tw), tx = (int)(p - (long long)ty * tw);
-        uint32_t tv = PPW_SENT;
-        if (ty > 0 && ty < th - 1 && tx > 0 && tx < tw - 1) {
-          const uint32_t j = (uint32_t)(y0 - 1 + ty) * (uint32_t)W + (uint32_t)(x0 - 1 + tx);
-          if (mask[j]) {
-            const int m = out[j];                         // = markers[j] (pp_markers_kernel)
-            const float v = img[j];
-            if (m != 0) {
-              if (mlab[j] == root) { is_marker = true; k0 = pp_key(v, 0u); j0 = j; l0 = m; }
-            } else {
-              tv = __float_as_uint(v);
-            }
-          }
-        }
-        if (lds) s_tile[p] = tv;
-      }
-      const unsigned long long bal = __ballot(is_marker);
-      if (is_marker) {
-        const int slot = total + __popcll(bal & lt_mask);
-        q_set_at(slot >> 6, slot & 63, k0, j0, l0);
-      }
-      total += __popcll(bal);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (;;) {
+      int c = 0;
+      if (lane == 0) c = atomicAdd(&counters[work_slot + pass], 1);
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (c >= ncomp) break;
+      const int root = clist[c];
+      const int area = carea[root];
+      if ((area >= PPW_BIG_AREA) != (pass == 0)) continue;
+      const int y0 = bymin[root], y1 = bymax[root], x0 = bxmin[root], x1 = bxmax[root];
+      const int th = y1 - y0 + 3, tw = x1 - x0 + 3;       // bounding box + 1 px rim
+      const long long px = (long long)th * tw;
+      if (px <= px_lo || px > px_hi) continue;            // the other launch's class
+      unsigned long long* gkey = hkey + hoff[root];
+      uint32_t* gidx = hidx + hoff[root];
+      int32_t* glab = hlab + hoff[root];
+#define PPW_RUN(L, S) ppw_component<L, S>(s_key, s_idx, s_lab, s_tile, img, mask, mlab, gkey, gidx, glab, out, H, W, root, \
+                                          y0, x0, th, tw, rows_lds)
+      if (px > (long long)tile_px || tw > 64 * 1024 || th > 32 * 1024) taint |= PPW_RUN(false, true);
+      else if (area > rows_lds * 64) taint |= PPW_RUN(true, true);
+      else taint |= PPW_RUN(true, false);                 // the queue can never outgrow its LDS rows
+#undef PPW_RUN
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // spilled rows were written by other lanes
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    cnt = total > lane ? (total - lane + 63) >> 6 : 0;
-    q_rescan();
-
-    // ---- flood ----
-    unsigned age = 0u;
-    unsigned long long prev0_key = ~0ull;   // tracking state of pp_flood<true>, uniform over the wave
-    int prev0_label = 0, since_prev0 = 0;
-    bool prev0_tied = false, sticky = false, watch_diff = false;
-    uint32_t pushed_prev[4] = {PPW_SENT, PPW_SENT, PPW_SENT, PPW_SENT};
-    unsigned pushed_prev_val[4] = {0u, 0u, 0u, 0u};
-    unsigned prev_val = 0xffffffffu, watch_val = 0u;
-    while (total > 0) {
-      // pop: smallest (value, age) over the cached column minima
-      const unsigned hi = cnt > 0 ? (unsigned)(mk >> 32) : 0xffffffffu;
-      const unsigned mh = ppw_wave_min(hi);
-      const unsigned lo = (cnt > 0 && hi == mh) ? (unsigned)mk : 0xffffffffu;
-      const unsigned ml = ppw_wave_min(lo);
-      const unsigned long long k = ((unsigned long long)mh << 32) | ml;
-      const int winner = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cnt > 0 && mk == k)) - 1);
-      uint32_t e = 0; int lab = 0;
-      if (lane == winner) {
-        e = q_idx(mrow); lab = q_lab(mrow);
-        const int last = cnt - 1;
-        if (mrow != last) q_set_at(mrow, lane, q_key(last), q_idx(last), q_lab(last));
-        cnt = last;
-        q_rescan();
-      }
-      e = (uint32_t)__builtin_amdgcn_readlane((int)e, winner);
-      lab = __builtin_amdgcn_readlane(lab, winner);
-      --total;
-      const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
-
-      bool tie = false, tie_diff = false, had_cascade = false;
-      {
-        const unsigned val = mh, a = ml;
-        if (sticky && val == prev_val) taint |= 16;                              // rule 3
-        if (watch_val && val < watch_val) {                                      // Y's cascade
-          if (watch_diff) taint |= 4;                                            // rule 2b
-          else sticky = true;                                                    // rule 3b
-        }
-        if (a == 0u) {
-          if (k == prev0_key) {
-            tie = true;
-            tie_diff = (lab != prev0_label);
-            if (prev0_tied) sticky = true;                                       // rule 3b (chain of ties)
-            had_cascade = since_prev0 > 0;
-            if (since_prev0 > 0) {
-              if (tie_diff) taint |= 2;                                          // rule 2a
-              else sticky = true;                                                // rule 3b
-            }
-            watch_val = val; watch_diff = tie_diff;
-          } else {
-            watch_val = 0u;
-          }
-          prev0_tied = tie;
-          prev0_key = k; prev0_label = lab; since_prev0 = 0;
-        } else {
-          ++since_prev0;
-        }
-        prev_val = val;
-      }
-
-      // neighbours in skimage's order up, left, right, down: lanes 0..3
-      bool push = false, valid = false;
-      uint32_t j = 0; unsigned long long nk = 0;
-      float v = 0.f;
-      if (lane < 4) {
-        const int dy = lane == 0 ? -1 : (lane == 3 ? 1 : 0), dx = lane == 1 ? -1 : (lane == 2 ? 1 : 0);
-        const int ny = y + dy, nx = x + dx;
-        valid = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
-        j = (uint32_t)((int)e + dy * W + dx);
-        if (lds) {
-          const int t = (ny - y0 + 1) * tw + (nx - x0 + 1);
-          const uint32_t tv = s_tile[t];
-          push = tv != PPW_SENT;
-          v = __uint_as_float(tv);
-          if (push) { s_tile[t] = PPW_SENT; out[j] = lab; }
-        } else if (valid && mask[j]) {
-          push = __hip_atomic_load(&out[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
-          if (push) {
-            v = img[j];
-            __hip_atomic_store(&out[j], lab, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
-        if (!push && tie_diff && valid &&
-            (j == pushed_prev[0] || j == pushed_prev[1] || j == pushed_prev[2] || j == pushed_prev[3]))
-          taint |= 1;                                                            // rule 1
-      }
-      unsigned pb = (unsigned)__ballot(push) & 0xfu;
-      if (push) nk = pp_key(v, age + 1u + (unsigned)__popc(pb & ((1u << lane) - 1u)));
-      age += (unsigned)__popc(pb);
-      uint32_t pushed_now[4] = {PPW_SENT, PPW_SENT, PPW_SENT, PPW_SENT};
-      unsigned pushed_now_val[4] = {0u, 0u, 0u, 0u};
-      bool first = true;
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
-        if (!((pb >> sl) & 1u)) continue;                                        // uniform
-        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nk >> 32), sl);
-        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)nk, sl);
-        const uint32_t js = (uint32_t)__builtin_amdgcn_readlane((int)j, sl);
-        const unsigned long long ks = ((unsigned long long)khi << 32) | klo;
-        pushed_now[sl] = js; pushed_now_val[sl] = khi;
-        int t = winner;                                   // the column that just lost a row ...
-        if (!first) t = (int)(ppw_wave_min(((unsigned)cnt << 6) | (unsigned)lane) & 63u);   // ... else the shortest one
-        first = false;
-        if (lane == t) {
-          q_set_at(cnt, lane, ks, js, lab);
-          if (ks < mk) { mk = ks; mrow = cnt; }
-          ++cnt;
-        }
-        ++total;
-      }
-      if (ml == 0u) {
-        if (tie && !had_cascade) {                                               // rule 3a
-#pragma unroll
-          for (int pp_ = 0; pp_ < 4; ++pp_)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (pushed_now[pp_] != PPW_SENT && pushed_prev[q] != PPW_SENT && pushed_now_val[pp_] == pushed_prev_val[q]) {
-                if (tie_diff) taint |= 8; else sticky = true;
-              }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { pushed_prev[q] = pushed_now[q]; pushed_prev_val[q] = pushed_now_val[q]; }
-      }
-    }
-    __syncthreads();                                      // the next component reuses the tile
   }
   if (taint) atomicOr(&counters[C_TAINT], taint);
 }
@@ -1149,12 +1189,14 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
                      (const int32_t*)w.scan, n, w.clist);
   // one wavefront per component: small boxes first (3 workgroups per CU), then the large ones (1 per CU)
   hipLaunchKernelGGL((pp_flood_wave_kernel<PPW_TILE_S>), dim3(256 * 3), dim3(64), 0, st, img, (const uint8_t*)w.mask,
-                     (const int32_t*)w.mlab, (const int32_t*)w.clist, (const int32_t*)w.hoff, (const int32_t*)w.bymin,
-                     (const int32_t*)w.bymax, (const int32_t*)w.bxmin, (const int32_t*)w.bxmax, w.hkey, w.hidx, w.scan,
+                     (const int32_t*)w.mlab, (const int32_t*)w.clist, (const int32_t*)w.hoff, (const int32_t*)w.carea,
+                     (const int32_t*)w.bymin, (const int32_t*)w.bymax, (const int32_t*)w.bxmin,
+                     (const int32_t*)w.bxmax, w.hkey, w.hidx, w.scan,
                      w.out, H, W, w.counters, (int)C_WORK_S, 0LL, (long long)g_ppw_tile_s, g_ppw_tile_s, g_ppw_rows);
   hipLaunchKernelGGL((pp_flood_wave_kernel<PPW_TILE_L>), dim3(256), dim3(64), 0, st, img, (const uint8_t*)w.mask,
-                     (const int32_t*)w.mlab, (const int32_t*)w.clist, (const int32_t*)w.hoff, (const int32_t*)w.bymin,
-                     (const int32_t*)w.bymax, (const int32_t*)w.bxmin, (const int32_t*)w.bxmax, w.hkey, w.hidx, w.scan,
+                     (const int32_t*)w.mlab, (const int32_t*)w.clist, (const int32_t*)w.hoff, (const int32_t*)w.carea,
+                     (const int32_t*)w.bymin, (const int32_t*)w.bymax, (const int32_t*)w.bxmin,
+                     (const int32_t*)w.bxmax, w.hkey, w.hidx, w.scan,
                      w.out, H, W, w.counters, (int)C_WORK_L, (long long)g_ppw_tile_s, 0x7fffffffffffffffLL, g_ppw_tile_l,
                      g_ppw_rows);
   if (force_serial) {
