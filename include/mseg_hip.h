@@ -101,6 +101,10 @@ int mseg_igemm(const MsegIgemm* p, void* stream);
 int mseg_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* bytes of split-K scratch this launch would use (0: it would not be split) */
 size_t mseg_igemm_workspace_bytes(const MsegIgemm* p);
+/* Test / ablation hook: on = 0 sends the 64 -> 64 channel bf16-storage layers (level 0 of the U-Nets) back to the
+ * tile-per-workgroup kernel instead of the persistent one that keeps the layer's weights in LDS.  Same results either
+ * way (the tests compare both).  Process-wide; default 1. */
+int mseg_igemm_set_persistent(int on);
 
 /* weight gradient: G[t][mch][nch] = sum_p P[p][mch] * Q[gather(p, t)][nch], written to dst[(mch*Nch + nch)*T + t]
  * which *is* torch's layout for both Conv2d.weight (Cout,Cin,KH,KW) [P = dz, Q = conv input] and

@@ -265,7 +265,8 @@ __device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
-          if (o != BAD) d[o] = acc[a][b][r] + bias + old[r];
+          const float v = acc[a][b][r] + bias + old[r];   // (unconditional use: no read-modify-write load stays pending
+          if (o != BAD) d[o] = v;                         //  past the epilogue in the compiler's wait-count bookkeeping)
         }
       };
       if (mode == 0) { emit(rel_affine); continue; }
@@ -1486,6 +1487,300 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
 }
 
+// ---- persistent bf16 kernel for the 64 -> 64 channel layers of level 0 ------------------------------------------------------
+// Level 0 has the most pixels and the fewest channels: 3 x 3 x 64 x 64 is 241 GFLOP per launch at 32 x 320 x 320 (0.1 ms
+// at the bf16 matrix peak) against 0.84 GB of bf16 tensors in and out (0.17 ms at 5 TB/s) — an HBM-bound layer.  The
+// tile-per-workgroup kernel above re-stages the layer's 74 KB of weights for every 128-pixel tile (three times the bytes
+// of the tile's halo) and runs at a third of that bound.  Here the weights of all nine taps stay in LDS for the lifetime
+// of a workgroup (one per CU), which walks pixel tiles: per step TWO independent 128-pixel tiles (one per group of four
+// waves, sharing the weights), their halos (64 channels per row) fetched into registers during the previous step's MFMAs
+// and written to LDS after them, labels of the step before stored while the next fetch is in flight.  64-bit global
+// addresses per halo row: no descriptor limits on frame or batch size.
+struct C64Cfg {
+  static constexpr int WN = 2, WM = 2;
+  static constexpr int TM = 64, TN = 32;
+  static constexpr int MB = 2, NB = 1;
+};
+#define C64_STRIDE 72           // bf16 per LDS row: 64 channels + 8 pad (144 B: conflict-free 16-byte reads of consecutive rows)
+#define C64_HPAD 208            // staging rows per tile (204 halo rows rounded up to a multiple of 8: a wave stays in one tile)
+
+// Workgroup barrier that orders LDS only: __syncthreads() also waits for every global store of the epilogue and every halo
+// load in flight (vmcnt(0)) — the two latencies this kernel exists to overlap.  Global memory needs no ordering here: the
+// workgroups write disjoint outputs and read tensors earlier launches produced.
+#define C64_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Barrier among the four waves of one tile group (there is one hardware barrier per workgroup, and the two groups must NOT
+// wait for each other): a monotonically increasing counter in LDS.  A wave's LDS operations execute in order, so whoever
+// sees its increment sees its earlier writes.  Every wave of a group passes the same number of these barriers.
+__device__ __forceinline__ void c64_group_barrier(unsigned* cnt, unsigned& target) {
+  target += 4u;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+// Two groups of four waves per workgroup, each walking its own sequence of 128-pixel tiles with its own halo buffer and its
+// own barriers; they only share the resident weights.  Running them out of step is the point: with all waves of a CU in the
+// same phase the vector instructions of the fetch / commit / store phases are hidden behind nobody's MFMAs (measured with
+// one common barrier: those phases cost more time than the 72 MFMAs of a tile), whereas a group's MFMAs now run under the
+// other group's loads, LDS writes and stores — what two co-resident workgroups would give, if two copies of the weights
+// fitted in LDS.  Everything a thread needs per tile besides the tile's origin is computed ONCE per launch (offsets of its
+// halo rows and of its output rows relative to the tile origin).
+template <int TR, bool D16>
+__global__ __launch_bounds__(512, 1) void igemm_c64p_bf16_kernel(const MsegIgemm p, int tw_log2, int ntiles) {
+  using Cfg = C64Cfg;
+  constexpr int HL = 7;                               // staging passes of a group: 208 rows x 8 threads over 256 threads
+  constexpr int NE = D16 ? 8 : 16;                    // stores per lane and 32-row block (bf16: channel pairs)
+  __shared__ __attribute__((aligned(16))) __bf16 lds[9 * 64 * C64_STRIDE + 2 * C64_HPAD * C64_STRIDE];
+  __shared__ unsigned gcount[2];
+  __bf16* const Wl = lds;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;                          // tile group of this wave
+  const int gtid = tid & 255;
+  __bf16* const Hl = lds + 9 * 64 * C64_STRIDE + grp * C64_HPAD * C64_STRIDE;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = gtid >> 3, scol = gtid & 7;        // staging: 32 rows x 8 groups of 8 channels per pass
+  const int TW = 1 << tw_log2, TH = 128 >> tw_log2, HW2 = TW + 2;
+  const int HROWS = (TH + 2) * HW2;
+  const int H = p.Hi, W = p.Wi;
+  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int tiles_img = tiles_x * tiles_y;
+  const bool conv = p.mode == MSEG_MODE_CONV;
+  const MsegSrc& s = p.src[0];
+  const __bf16* const srcp = reinterpret_cast<const __bf16*>(s.ptr);
+
+  // halo rows of this thread: position inside the halo (hy, hx) and element offset from the halo's first pixel
+  // (image position (oy0 - 1, ox0 - 1) — possibly outside the image; such rows are never dereferenced)
+  int hyx[HL], roff[HL];
+  unsigned hgeo = 0u;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int hrow = srow + 32 * j;
+    const int hy = hrow / HW2, hx = hrow - hy * HW2;
+    hyx[j] = (hy << 16) | hx;
+    roff[j] = (hy * W + hx) * 64 + scol * 8;
+    hgeo |= (unsigned)(hrow < HROWS) << j;
+  }
+  const int roff_safe = (W + 1) * 64 + scol * 8;      // the tile's own first pixel: always inside the image
+  int abase[Cfg::MB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a) {
+    const int i = wm * Cfg::TM + a * 32 + li;
+    abase[a] = ((i >> tw_log2) * HW2 + (i & (TW - 1))) * C64_STRIDE + lh * 8;
+  }
+  // output rows of this lane: element offset from the tile's first output pixel, and the row's dy (rows past the image's
+  // last row — only possible in the bottom tile row — are skipped)
+  const int n_out = wn * 32 + li;                     // this lane's output channel
+  const bool odd = li & 1;
+  const int ld = p.ld0;
+  int eoff[Cfg::MB][NE], edy[Cfg::MB][NE];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int r = D16 ? 2 * e + (odd ? 1 : 0) : e;
+      const int i = wm * Cfg::TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      edy[a][e] = i >> tw_log2;
+      eoff[a][e] = ((i >> tw_log2) * W + (i & (TW - 1))) * ld + n_out - (D16 && odd ? 1 : 0);
+    }
+  const bool nvalid = n_out < p.Ngemm;
+  const float bias = (p.bias && nvalid) ? p.bias[n_out] : 0.f;
+  const int accf = p.acc0;
+
+  // the layer's weights, all nine taps: [tap][n < 64][k < 64] bf16, resident for the whole launch
+  {
+    const __bf16* const wp = reinterpret_cast<const __bf16*>(p.w);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int idx = tid + 512 * i;                   // 9 x 64 rows x 8 column groups = 4608
+      const int row = idx >> 3, c8 = idx & 7;
+      const int tap = row >> 6, n = row & 63;
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + ((size_t)tap * p.Npad + n) * p.Kpad + c8 * 8);
+      *reinterpret_cast<uint4*>(Wl + row * C64_STRIDE + c8 * 8) = v;
+    }
+    if (tid < 2) gcount[tid] = 0u;
+  }
+  __syncthreads();                                     // the only workgroup-wide barrier
+
+  uint4 rh[HL];
+  unsigned hlive = 0u;
+  float4 tsc[2], tsh[2];                               // norm-on-load tables of this thread's 8 channels (per tile: per-sample norms)
+  int ract = 0;
+
+  auto decode = [&](int t, int& img, int& oy, int& ox) {
+    img = t / tiles_img;
+    const int trem = t - img * tiles_img;
+    const int ty = trem / tiles_x;
+    oy = ty * TH; ox = (trem - ty * tiles_x) * TW;
+  };
+
+  auto issue_halo = [&](int t) {
+    int img, oy, ox;
+    decode(t, img, oy, ox);
+    // first pixel of the tile's halo (wave-uniform 64-bit base; the per-row offsets are 32-bit and launch-invariant)
+    const __bf16* const hb = srcp + (((long long)img * H + oy - 1) * W + ox - 1) * 64;
+    hlive = 0u;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const int iy = oy - 1 + (hyx[j] >> 16), ix = ox - 1 + (hyx[j] & 0xffff);
+      const bool live = ((hgeo >> j) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      // always load (a dead row reads the tile's first pixel and is zeroed when written to LDS): a conditional load would
+      // be merged with its zero right here, i.e. waited for BEFORE the MFMAs it is meant to overlap
+      rh[j] = *reinterpret_cast<const uint4*>(hb + (live ? roff[j] : roff_safe));
+      hlive |= (unsigned)live << j;
+    }
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + scol * 8;
+      tsc[0] = *reinterpret_cast<const float4*>(scp + o); tsc[1] = *reinterpret_cast<const float4*>(scp + o + 4);
+      tsh[0] = *reinterpret_cast<const float4*>(shp + o); tsh[1] = *reinterpret_cast<const float4*>(shp + o + 4);
+    }
+  };
+
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    return v;
+  };
+
+  auto commit_halo = [&]() {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      if (!((hgeo >> j) & 1u)) continue;
+      uint4 v = rh[j];
+      if (TR != 0) {                                    // (TR == 0: a plain bf16 operand is already in LDS format)
+        const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
+        const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
+        const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+        v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+      }
+      if (!((hlive >> j) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);     // zero padding / rows outside the image
+      *reinterpret_cast<uint4*>(Hl + (srow + 32 * j) * C64_STRIDE + scol * 8) = v;
+    }
+  };
+
+  // stores of one finished tile: straight-line, every read-modify-write load unconditional (rows past the image re-read the
+  // tile's first row) and consumed before the first store — nothing stays pending across the loop's back edge
+  auto store_tile = [&](f32x16 (&acc)[Cfg::MB][Cfg::NB], int img, int oy0, int ox0) {
+    if (!nvalid) return;
+    const int rows_in = H - oy0;                        // image rows left from the tile's first row
+    if (D16) {
+      __bf16* const d = reinterpret_cast<__bf16*>(p.dst0) + (((long long)img * H + oy0) * W + ox0) * ld;
+      unsigned oldw[Cfg::MB][NE];
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) oldw[a][e] = 0u;
+      if (accf) {
+#pragma unroll
+        for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+          for (int e = 0; e < NE; ++e)
+            oldw[a][e] = *reinterpret_cast<const unsigned*>(d + (edy[a][e] < rows_in ? eoff[a][e] : eoff[a][0] - edy[a][0] * W * ld));
+        // pin the consumption here: the compiler sinks the additions below into the per-lane store branches, which leaves
+        // these loads "pending" on the other path — and makes it wait for EVERY outstanding load and store at the top of
+        // the next trip
+#pragma unroll
+        for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(oldw[a][e]));
+      }
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          // lanes 2k / 2k+1 hold channels n, n+1 of the same rows: they swap halves through a DPP quad permute, the even
+          // lane stores the channel PAIR of the even accumulator rows and the odd lane that of the odd rows
+          const float mine_e = acc[a][0][2 * e] + bias, mine_o = acc[a][0][2 * e + 1] + bias;
+          const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+          const float lo = (odd ? got : keep) + bf16_lo(oldw[a][e]), hi = (odd ? keep : got) + bf16_hi(oldw[a][e]);
+          const unsigned v = pack_bf16x2(lo, hi);
+          if (edy[a][e] < rows_in) *reinterpret_cast<unsigned*>(d + eoff[a][e]) = v;
+        }
+      }
+    } else {
+      float* const d = reinterpret_cast<float*>(p.dst0) + (((long long)img * H + oy0) * W + ox0) * ld;
+#pragma unroll
+      for (int a = 0; a < Cfg::MB; ++a) {
+        float old[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) old[e] = 0.f;
+        if (accf) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) old[e] = d[edy[a][e] < rows_in ? eoff[a][e] : eoff[a][0] - edy[a][0] * W * ld];
+#pragma unroll
+          for (int e = 0; e < NE; ++e) asm volatile("" : "+v"(old[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float v = acc[a][0][e] + bias + old[e];
+          if (edy[a][e] < rows_in) d[eoff[a][e]] = v;
+        }
+      }
+    }
+  };
+
+  // tiles of this group: 2 * lid + grp, then every 2 * G-th (neighbouring tiles — which share halo rows — run at the same
+  // time on one XCD's L2)
+  const int stride = 2 * (int)gridDim.x;
+  int t = 2 * (int)xcd_logical_id(blockIdx.x, gridDim.x) + grp;
+  unsigned gb_target = 0u;
+  unsigned* const gcnt = &gcount[grp];
+  // Software pipeline: the halo of tile t + 2 * stride is fetched (into registers) right after the one of t + stride went to
+  // LDS, i.e. before the stores of tile t; it has those stores, a barrier and the MFMAs of t + stride to arrive.
+  if (t < ntiles) {
+    issue_halo(t);
+    commit_halo();
+    if (t + stride < ntiles) issue_halo(t + stride);
+    c64_group_barrier(gcnt, gb_target);
+  }
+  for (; t < ntiles; t += stride) {
+    const int next = t + stride;
+    f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+    for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+    {
+      const __bf16* Wt = Wl + (wn * Cfg::TN + li) * C64_STRIDE + lh * 8;
+      int ky = 0, kx = 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * C64_STRIDE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Wt + kk * 16);
+#pragma unroll
+          for (int a = 0; a < Cfg::MB; ++a) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Hl + abase[a] + toff + kk * 16);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[a][0], 0, 0, 0);
+          }
+        }
+        Wt += 64 * C64_STRIDE;
+        if (++kx == 3) { kx = 0; ++ky; }
+      }
+    }
+    c64_group_barrier(gcnt, gb_target);                 // the group is done reading this tile's halo
+    if (next < ntiles) {
+      commit_halo();
+      if (next + stride < ntiles) issue_halo(next + stride);
+    }
+    int e_img, e_oy, e_ox;
+    decode(t, e_img, e_oy, e_ox);
+    store_tile(acc, e_img, e_oy, e_ox);
+    c64_group_barrier(gcnt, gb_target);                 // the next halo is in LDS
+  }
+}
+
 // ---- bf16 variant of the gather kernel (stride-2 convolutions, ConvTranspose as a 1x1 GEMM, their data gradients) ----
 // igemm_fast_kernel with bf16 matrix-core inputs: same per-row offsets / tap masks / live-tap list and epilogue; the staged
 // source pixels are rounded to bf16 after the norm-on-load transform, the weights arrive as bf16, LDS rows are 32 bf16 +
@@ -1761,6 +2056,26 @@ static int halo_ksplit(long long htiles, int nchunks, int* chunks_per_split) {
   return (nchunks + *chunks_per_split - 1) / *chunks_per_split;     // splits that actually get chunks
 }
 
+static int g_c64p_on = 1;
+// Test / ablation hook: 0 sends the 64 -> 64 channel bf16 layers back to the tile-per-workgroup kernel.  Process-wide.
+extern "C" int mseg_igemm_set_persistent(int on) {
+  g_c64p_on = on ? 1 : 0;
+  return MSEG_OK;
+}
+
+// one persistent workgroup per compute unit of the current device
+static int c64p_workgroups() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 static bool halo_geometry(const MsegIgemm& p, int BNv, int* tw_log2_out, long long* htiles_out) {
   if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0))
@@ -1898,7 +2213,19 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     if (s16) hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, true>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);    \
     else hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, false>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);       \
   } while (0)
-    if (p.precision == MSEG_PREC_BF16) {
+    if (p.precision == MSEG_PREC_BF16 && s16 && !wide && g_c64p_on && p.nsrc == 1 && p.Cin == 64 && p.Kpad == 64 &&
+        ks == 1 && tw_log2 <= 5 && p.split >= p.Ngemm && htiles >= 4 * (long long)c64p_workgroups()) {
+      // 64 -> 64 channels on bf16 tensors (level 0): persistent workgroups that keep the layer's weights in LDS
+      const int wgs = c64p_workgroups();
+      const dim3 pgrid((unsigned)wgs);                      // htiles >= 4 per workgroup: every group has work
+#define MSEG_C64P(TR_)                                                                                                        \
+  do {                                                                                                                         \
+    if (q.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_c64p_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles); \
+    else hipLaunchKernelGGL((igemm_c64p_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles);               \
+  } while (0)
+      if (tr == 0) MSEG_C64P(0); else if (tr == 1) MSEG_C64P(1); else MSEG_C64P(2);
+#undef MSEG_C64P
+    } else if (p.precision == MSEG_PREC_BF16) {
       if (wide) { if (tr == 0) MSEG_HALO16W4(0); else if (tr == 1) MSEG_HALO16W4(1); else MSEG_HALO16W4(2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }
     } else if (wide) { if (tr == 0) MSEG_HALO(128, 0); else if (tr == 1) MSEG_HALO(128, 1); else MSEG_HALO(128, 2); }

@@ -517,6 +517,18 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
         name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
             "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")
         name = name[:-1] + (", true>" if srcs[0].dtype == ST_BF16 else ", false>")      # S16: bf16-stored operands
+        # 64 -> 64 channels on bf16 tensors with enough pixel tiles and no split-K: the persistent kernel (mirror of the
+        # launcher's rule in csrc/igemm.hip)
+        if name.startswith("igemm_halo_bf16_kernel<64") and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and \
+                p.Cin == 64 and w.Kpad == 64 and p.split >= Ngemm and need == 0:
+            tw = 32
+            while Wi % tw:
+                tw //= 2
+            th = 128 // tw
+            tiles = NB * ((Hi + th - 1) // th) * (Wi // tw)
+            if tiles >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+                tr = name.split(",")[1].strip()
+                name = "igemm_c64p_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
     e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")

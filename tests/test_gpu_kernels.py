@@ -821,3 +821,58 @@ def test_bf16_storage_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
     eng.wgrad(eng.plain_src(dz, Cout), qs, dW, N, H, W, H, W, 3, 3, 1, 1, eng.Workspace(torch.device("cuda")),
               precision="bf16")
     assert rel_err(dW.cpu(), w.grad) < 5e-4
+
+
+@pytest.mark.parametrize("N,H,W,act,per_sample,Cout", [(8, 128, 128, "relu", False, 64), (15, 120, 80, "relu", True, 64),
+                                                        (9, 122, 128, "mish", False, 64), (40, 60, 56, "none", False, 48)])
+def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample, Cout):
+    """64 -> 64 channel 3x3 layers on bf16 tensors with enough pixel tiles take the persistent kernel (weights of all nine
+    taps resident in LDS, two pixel tiles per step): forward with norm-on-load sources (per-channel and per-sample tables,
+    cheap and expensive activations), data gradient with a plain operand and accumulate, tiles narrower than 32 pixels,
+    image heights that are no multiple of the tile height, odd tile counts, fewer than 64 output channels.  Checked against
+    torch on the rounded operands AND against the tile-per-workgroup kernel (mseg_igemm_set_persistent(0))."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    Cin = 64
+    g = torch.Generator().manual_seed(900 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    nsc = (N, Cin) if per_sample else (Cin,)
+    scale, shift = rnd(g, *nsc) * 0.3 + 1.0, rnd(g, *nsc) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z16.float(), act, scale, shift, per_sample)), _bf(w), b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    node = _mk_node(eng, z16.float(), act, scale, shift, per_sample)
+    node.z = node.z.to(torch.bfloat16)
+    src = node.src()
+    outs = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_persistent(on) == 0
+        try:
+            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            eng.igemm([src], wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_persistent(1)
+    tol = 6e-3 if act != "mish" else 8e-3               # one bf16 rounding of the stored result (+ the fast Mish flavour)
+    assert rel_err(nchw(outs[0]), ref) < tol
+    assert rel_err(outs[0], outs[1]) < 8e-3              # same operands, another fp32 accumulation order: at most one bf16 ulp
+    if Cout != 64:
+        return
+    # data gradient (transposed convolution): plain bf16 operand, accumulate into a bf16 destination
+    gy16 = _b16(rnd(g, N, Cout, H, W))
+    refn = nhwc(F.conv_transpose2d(gy16.float(), _bf(w), None, padding=1))
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    base = _b16(rnd(g, N, H, W, Cin))
+    dz = nhwc(gy16).cuda()
+    got = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_persistent(on) == 0
+        try:
+            d0 = base.clone().cuda()
+            eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, Cin, acc0=1,
+                      precision="bf16")
+            got.append(d0.float().cpu())
+        finally:
+            lib.mseg_igemm_set_persistent(1)
+    assert rel_err(got[0], refn + base.float()) < 6e-3
+    assert rel_err(got[0], got[1]) < 8e-3
