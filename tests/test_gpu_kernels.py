@@ -823,12 +823,14 @@ def test_bf16_storage_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
     assert rel_err(dW.cpu(), w.grad) < 5e-4
 
 
-@pytest.mark.parametrize("N,H,W,act,per_sample,Cout", [(8, 128, 128, "relu", False, 64), (15, 120, 80, "relu", True, 64),
-                                                        (9, 122, 128, "mish", False, 64), (40, 60, 56, "none", False, 48)])
-def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample, Cout):
+@pytest.mark.parametrize("N,H,W,act,per_sample,Cout,dst32", [
+    (8, 128, 128, "relu", False, 64, False), (15, 120, 80, "relu", True, 64, False), (9, 122, 128, "mish", False, 64, False),
+    (40, 60, 56, "none", False, 48, False), (8, 128, 128, "relu", False, 64, True)])
+def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample, Cout, dst32):
     """64 -> 64 channel 3x3 layers on bf16 tensors with enough pixel tiles take the persistent kernel (weights of all nine
     taps resident in LDS, two pixel tiles per step): forward with norm-on-load sources (per-channel and per-sample tables,
-    cheap and expensive activations), data gradient with a plain operand and accumulate, tiles narrower than 32 pixels,
+    cheap and expensive activations), data gradient with a plain operand and accumulate, bf16 and fp32 destinations, tiles
+    narrower than 32 pixels,
     image heights that are no multiple of the tile height, odd tile counts, fewer than 64 output channels.  Checked against
     torch on the rounded operands AND against the tile-per-workgroup kernel (mseg_igemm_set_persistent(0))."""
     from microbeseg_amd import _lib
@@ -848,7 +850,7 @@ def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample
     for on in (1, 0):
         assert lib.mseg_igemm_set_persistent(on) == 0
         try:
-            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32 if dst32 else torch.bfloat16)
             eng.igemm([src], wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
             outs.append(out.float().cpu())
         finally:
@@ -863,6 +865,8 @@ def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample
     refn = nhwc(F.conv_transpose2d(gy16.float(), _bf(w), None, padding=1))
     wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
     base = _b16(rnd(g, N, H, W, Cin))
+    if dst32:
+        base = base.float()
     dz = nhwc(gy16).cuda()
     got = []
     for on in (1, 0):
