@@ -58,6 +58,141 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
   }
 }
 
+// ---- row-walking forms for Cin = 1 (every reference configuration) ---------------------------------------------------------
+// The per-pixel form above spends ~300 index / bounds instructions (a 64-bit division per pixel) on 36 multiply-adds and
+// stores 8 bytes per lane: 1.1 TB/s on a layer that only has to write z.  Here a thread owns 8 output channels (16-byte
+// bf16 stores; 8 lanes = one pixel's 128 contiguous bytes) of one image COLUMN and walks FR_ROWS rows with the 3 x 3 input
+// window in registers (3 new values per row), so a pixel costs 3 loads, 72 multiply-adds and one store, no divisions.
+// Same accumulation order as above (bias, then taps row-major; a tap outside the image adds 0).
+#define FR_ROWS 8
+
+template <bool S16>
+__global__ __launch_bounds__(256) void first_conv_fwd_rows_kernel(const float* __restrict__ x4, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, int H, int W, int Cout,
+                                                                  void* __restrict__ z) {
+  const int CG = Cout >> 3;                  // channel groups of 8
+  const int XS = 256 / CG;                   // image columns per workgroup
+  const int cg = threadIdx.x % CG, xs = threadIdx.x / CG;
+  const int co = cg * 8;
+  float wr[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = w[(size_t)(co + j) * 9 + t];
+  float b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = bias ? bias[co + j] : 0.f;
+  const int x = blockIdx.x * XS + xs, y0 = blockIdx.y * FR_ROWS, n = blockIdx.z;
+  if (x >= W) return;
+  const float* const img = x4 + (size_t)n * H * W * 4;
+  auto px = [&](int yy, int xx) -> float {
+    return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[((size_t)yy * W + xx) * 4] : 0.f;
+  };
+  float win[3][3];                           // rows y - 1, y, y + 1; columns x - 1, x, x + 1
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { win[0][k] = px(y0 - 1, x - 1 + k); win[1][k] = px(y0, x - 1 + k); }
+  const int yend = y0 + FR_ROWS < H ? y0 + FR_ROWS : H;
+  for (int y = y0; y < yend; ++y) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) win[2][k] = px(y + 1, x - 1 + k);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = b[j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += win[ky][kx] * wr[j][ky * 3 + kx];
+    const size_t e = (((size_t)n * H + y) * W + x) * Cout + co;
+    if (S16) {
+      const uint2 lo = f32x4_to_bf16(make_float4(acc[0], acc[1], acc[2], acc[3]));
+      const uint2 hi = f32x4_to_bf16(make_float4(acc[4], acc[5], acc[6], acc[7]));
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(z) + e) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      float* const zp = reinterpret_cast<float*>(z) + e;
+      *reinterpret_cast<float4*>(zp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(zp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { win[0][k] = win[1][k]; win[1][k] = win[2][k]; }
+  }
+}
+
+// weight gradient, same walk: a thread accumulates 9 taps x 8 channels over the rows of its units (unit = FR_ROWS rows of
+// XS columns of one image; units dealt round-robin to the workgroups), then the workgroup combines its 256 / CG columns in
+// fixed order.  part[block][9][Cout] as in the per-pixel form.
+template <bool S16>
+__global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const float* __restrict__ x4, const void* __restrict__ dz,
+                                                               int N, int H, int W, int Cout, float* __restrict__ part) {
+  __shared__ float fr_red[9 * 2048];         // [9][XS][Cout]; XS * Cout = 256 threads x 8 channels for every shape
+  const int CG = Cout >> 3, XS = 256 / CG;
+  const int cg = threadIdx.x % CG, xs = threadIdx.x / CG;
+  const int co = cg * 8;
+  const int ubx = (W + XS - 1) / XS, uby = (H + FR_ROWS - 1) / FR_ROWS;
+  const int units = N * uby * ubx;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n = u / (uby * ubx);
+    const int r = u - n * (uby * ubx);
+    const int by = r / ubx, bx = r - by * ubx;
+    const int x = bx * XS + xs, y0 = by * FR_ROWS;
+    if (x >= W) continue;
+    const float* const img = x4 + (size_t)n * H * W * 4;
+    auto px = [&](int yy, int xx) -> float {
+      return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[((size_t)yy * W + xx) * 4] : 0.f;
+    };
+    float win[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { win[0][k] = px(y0 - 1, x - 1 + k); win[1][k] = px(y0, x - 1 + k); }
+    const int yend = y0 + FR_ROWS < H ? y0 + FR_ROWS : H;
+    // (measured: fetching the next row's dz one trip ahead made the pass slower, 182 -> 228 us; the hardware's own
+    // multi-wave overlap is enough)
+    for (int y = y0; y < yend; ++y) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) win[2][k] = px(y + 1, x - 1 + k);
+      const size_t e = (((size_t)n * H + y) * W + x) * Cout + co;
+      float g[8];
+      if (S16) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(dz) + e);
+        g[0] = bf16_lo(raw.x); g[1] = bf16_hi(raw.x); g[2] = bf16_lo(raw.y); g[3] = bf16_hi(raw.y);
+        g[4] = bf16_lo(raw.z); g[5] = bf16_hi(raw.z); g[6] = bf16_lo(raw.w); g[7] = bf16_hi(raw.w);
+      } else {
+        const float* const gp = reinterpret_cast<const float*>(dz) + e;
+        const float4 a = *reinterpret_cast<const float4*>(gp), c = *reinterpret_cast<const float4*>(gp + 4);
+        g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = c.x; g[5] = c.y; g[6] = c.z; g[7] = c.w;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += g[j] * win[ky][kx];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { win[0][k] = win[1][k]; win[1][k] = win[2][k]; }
+    }
+  }
+  // combine the columns of the workgroup (fixed order), one (tap, channel) per thread
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fr_red[(t * XS + xs) * Cout + co + j] = acc[t][j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * Cout; e += 256) {
+    const int t = e / Cout, c = e - t * Cout;
+    float s = 0.f;
+    for (int k = 0; k < XS; ++k) s += fr_red[(t * XS + k) * Cout + c];
+    part[((size_t)blockIdx.x * 9 + t) * Cout + c] = s;
+  }
+}
+
+// shapes the row-walking kernels take: Cin = 1, 8-channel groups that tile a 256-thread workgroup
+static bool first_rows_ok(int Cin, int Cout) { return Cin == 1 && (Cout & 7) == 0 && (256 % (Cout >> 3)) == 0 && Cout <= 256; }
+
 // dW[co][0][t] = sum_p dz[p][co] * x[p + tap t][0]   (Cin = 1).  Stage 1: every workgroup reduces a contiguous pixel range
 // into part[block][9][Cout]; stage 2 sums the blocks in fixed order (deterministic, fp64).
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restrict__ x4, const void* __restrict__ dz,
@@ -109,23 +244,24 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const float* __restric
   }
 }
 
-// fixed-order sum over the workgroup partials: 32 outputs x 8 partial groups per workgroup, combined through LDS
+// fixed-order sum over the workgroup partials: 8 outputs x 32 partial groups per workgroup, combined through LDS (a thread
+// walks nblocks / 32 partials: with 32 outputs x 8 groups this tiny kernel took as long as the streaming pass it finishes)
 __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout,
                                                                  float* __restrict__ dW) {
-  __shared__ double red[8][32];
-  const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + o;
+  __shared__ double red[32][8];
+  const int o = threadIdx.x & 7, kg = threadIdx.x >> 3;
+  const int e = blockIdx.x * 8 + o;
   const bool live = e < 9 * Cout;
   const int t = live ? e / Cout : 0, c = live ? e - t * Cout : 0;
   double s = 0.0;
   if (live)
-    for (int b = kg; b < nblocks; b += 8) s += (double)part[((size_t)b * 9 + t) * Cout + c];
+    for (int b = kg; b < nblocks; b += 32) s += (double)part[((size_t)b * 9 + t) * Cout + c];
   red[kg][o] = s;
   __syncthreads();
   if (kg == 0 && live) {
     double v = 0.0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v += red[j][o];
+    for (int j = 0; j < 32; ++j) v += red[j][o];
     dW[(size_t)c * 9 + t] = (float)v;          // torch layout (Cout, 1, 3, 3)
   }
 }
@@ -151,6 +287,16 @@ extern "C" int mseg_first_conv_fwd(const float* x4, const float* w, const float*
   if (!x4 || !w || !z || !first_shape_ok(N, H, W, Cin, Cout)) return MSEG_EINVAL;
   if (z_dtype != MSEG_ST_F32 && z_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
   const long long P = (long long)N * H * W;
+  if (first_rows_ok(Cin, Cout) && (H + FR_ROWS - 1) / FR_ROWS <= 65535 && N <= 65535) {
+    const int XS = 256 / (Cout >> 3);
+    const dim3 grid((unsigned)((W + XS - 1) / XS), (unsigned)((H + FR_ROWS - 1) / FR_ROWS), (unsigned)N);
+    if (z_dtype == MSEG_ST_BF16)
+      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z);
+    else
+      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z);
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
   const int ppb = 256 / (Cout >> 2);
   long long blocks = (P + ppb - 1) / ppb;
   if (blocks > 8192) blocks = 8192;
@@ -178,10 +324,24 @@ extern "C" int mseg_first_wgrad(const float* x4, const void* dz, int dz_dtype, i
   int per;
   const int blocks = first_blocks((long long)N * H * W, Cout, &per);
   hipStream_t st = (hipStream_t)stream;
+  const int XS = 256 / (Cout >> 3 ? Cout >> 3 : 1);
+  const long long units = first_rows_ok(1, Cout) ? (long long)N * ((H + FR_ROWS - 1) / FR_ROWS) * ((W + XS - 1) / XS) : 0;
+  if (units > 0 && units <= 0x7fffffffLL) {
+    const unsigned g = (unsigned)(units < blocks ? units : blocks);   // part[] rows beyond g stay unused: reduce over g
+    if (dz_dtype == MSEG_ST_BF16)
+      hipLaunchKernelGGL((first_wgrad_rows_kernel<true>), dim3(g), dim3(256), 0, st, x4, dz, N, H, W, Cout, (float*)ws);
+    else
+      hipLaunchKernelGGL((first_wgrad_rows_kernel<false>), dim3(g), dim3(256), 0, st, x4, dz, N, H, W, Cout, (float*)ws);
+    MSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 7) / 8), dim3(256), 0, st, (const float*)ws, (int)g,
+                       Cout, dW);
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
   hipLaunchKernelGGL(first_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x4, dz, dz_dtype, N, H, W, Cout,
                      per, (float*)ws);
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks,
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((9 * Cout + 7) / 8), dim3(256), 0, st, (const float*)ws, blocks,
                      Cout, dW);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;

@@ -314,7 +314,8 @@ def test_head_forward_backward(eng, Cc, Co):
     assert rel_err(db.cpu(), b.grad) < TOL
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 64, 24, 40), (1, 3, 16, 17, 9), (3, 1, 8, 32, 32)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 64, 24, 40), (1, 3, 16, 17, 9), (3, 1, 8, 32, 32), (2, 1, 64, 19, 50),
+                                           (1, 1, 32, 9, 70), (5, 1, 64, 64, 64)])
 def test_first_layer_kernels(eng, N, Cin, Cout, H, W):
     """Conv2d(ch_in, Cout, 3, padding=1) on the raw (zero-padded to 4 channels) input + its weight gradient (ch_in 1)."""
     from microbeseg_amd import _lib
