@@ -997,12 +997,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // S16: the sources are bf16 tensors (MSEG_ST_BF16).  A thread then stages 8 channels per 16-byte load (half the loads and LDS
 // writes of the fp32-source form); a plain operand (TR = 0) goes to LDS as it arrives.
-template <int BN, int TR, bool S16>
-__global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
-                                                                 int chunks_per_split, int m_fastest) {
-  constexpr int BM = 128;
-  using Cfg = HaloCfg<BN>;
-  constexpr int HMAX = 204;                          // (4 + 2) x (32 + 2), the largest halo (tw_log2 <= 5)
+// BM: pixels per tile.  128 everywhere except the 128 -> 64 channel layers of level 0 (igemm_halo_bf16m512_kernel below).
+template <int BN, int BM>
+struct HaloCfgM {
+  static constexpr int WN = (BN >= 128) ? 4 : 2;
+  static constexpr int WM = 8 / WN;
+  static constexpr int TM = BM / WM, TN = BN / WN;
+  static constexpr int MB = TM / 32, NB = TN / 32;
+  static constexpr int BROWS = BN / 64;
+};
+
+template <int BN, int TR, bool S16, int BM>
+__device__ __forceinline__ void igemm_halo_bf16_body(const MsegIgemm& p, int tw_log2, int ksplit, int chunks_per_split,
+                                                     int m_fastest) {
+  using Cfg = HaloCfgM<BN, BM>;
+  // largest halo: BM = 128: (4 + 2) x (32 + 2) (tw_log2 <= 5); BM = 512: (16 + 2) x (32 + 2) = (32 + 2) x (16 + 2) (tw_log2 4, 5)
+  constexpr int HMAX = BM == 128 ? 204 : 612;
   constexpr int SQ = S16 ? 4 : 8;                    // staging threads per halo row (8 / 4 channels each)
   constexpr int SROWS = 512 / SQ;                    // halo rows per staging pass
   constexpr int HL = (HMAX + SROWS - 1) / SROWS;     // 16-byte loads per thread per chunk (4; 2 for bf16 sources)
@@ -1224,6 +1234,23 @@ __global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(
     }
   }
   igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
+}
+
+template <int BN, int TR, bool S16>
+__global__ __launch_bounds__(512, BN == 64 ? 3 : 2) void igemm_halo_bf16_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                 int chunks_per_split, int m_fastest) {
+  igemm_halo_bf16_body<BN, TR, S16, 128>(p, tw_log2, ksplit, chunks_per_split, m_fastest);
+}
+
+// 512-pixel tiles for layers with few output channels and many input channels (128 -> 64 at level 0: the concat convolutions
+// of the decoders).  Their weights (147 KB) cannot stay resident like those of the 64 -> 64 layers, and with 128-pixel tiles
+// every tile re-stages all of them — 5.6 x the bytes of its halo.  Four pixel tiles per weight stage: a quarter of the
+// weight traffic into LDS, a wave owns 128 pixels x 32 channels (1.25 LDS reads per MFMA instead of 2), the halo shrinks
+// from 1.59 to 1.20 input rows per output row.  80 KB of LDS: two workgroups per CU.
+template <int TR, bool S16>
+__global__ __launch_bounds__(512, 2) void igemm_halo_bf16m512_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                     int chunks_per_split, int m_fastest) {
+  igemm_halo_bf16_body<64, TR, S16, 512>(p, tw_log2, ksplit, chunks_per_split, m_fastest);
 }
 
 // ---- 4-wave form of the bf16 halo kernel for BN = 128 --------------------------------------------------------------------
@@ -2076,6 +2103,15 @@ static int c64p_workgroups() {
   return cached[dev];
 }
 
+// 512-pixel tiles (igemm_halo_bf16m512_kernel): tile count, or 0 when more than a fifth of the tile rows would fall below
+// the image
+static long long halo512_tiles(const MsegIgemm& p, int tw_log2) {
+  const int TH = 512 >> tw_log2;
+  const long long rows = (long long)((p.Hi + TH - 1) / TH) * TH;
+  if ((long long)p.Hi * 5 < rows * 4) return 0;
+  return (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
+}
+
 static bool halo_geometry(const MsegIgemm& p, int BNv, int* tw_log2_out, long long* htiles_out) {
   if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.epi == MSEG_EPI_PLAIN && p.morder == MSEG_MORDER_LINEAR && (p.Wi % 4) == 0))
@@ -2225,6 +2261,17 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   } while (0)
       if (tr == 0) MSEG_C64P(0); else if (tr == 1) MSEG_C64P(1); else MSEG_C64P(2);
 #undef MSEG_C64P
+    } else if (p.precision == MSEG_PREC_BF16 && !wide && g_c64p_on && p.Cin >= 128 && ks == 1 && tw_log2 >= 4 &&
+               halo512_tiles(p, tw_log2) >= 2 * (long long)c64p_workgroups()) {
+      // few output channels, many input channels (the 128 -> 64 concat convolutions of level 0): 512-pixel tiles
+      const dim3 mgrid((unsigned)halo512_tiles(p, tw_log2));
+#define MSEG_HALO512(TR_)                                                                                                      \
+  do {                                                                                                                         \
+    if (s16) hipLaunchKernelGGL((igemm_halo_bf16m512_kernel<TR_, true>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);      \
+    else hipLaunchKernelGGL((igemm_halo_bf16m512_kernel<TR_, false>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);         \
+  } while (0)
+      if (tr == 0) MSEG_HALO512(0); else if (tr == 1) MSEG_HALO512(1); else MSEG_HALO512(2);
+#undef MSEG_HALO512
     } else if (p.precision == MSEG_PREC_BF16) {
       if (wide) { if (tr == 0) MSEG_HALO16W4(0); else if (tr == 1) MSEG_HALO16W4(1); else MSEG_HALO16W4(2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }

@@ -529,6 +529,15 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             if tiles >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
                 tr = name.split(",")[1].strip()
                 name = "igemm_c64p_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
+        elif name.startswith("igemm_halo_bf16_kernel<64") and p.Cin >= 128 and need == 0 and Wi % 16 == 0:
+            # few output channels, many input channels (the 128 -> 64 concat convolutions): 512-pixel tiles
+            tw = 32 if Wi % 32 == 0 else 16
+            th = 512 // tw
+            rows = (Hi + th - 1) // th * th
+            tiles = NB * (rows // th) * (Wi // tw)
+            if Hi * 5 >= rows * 4 and tiles >= 2 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+                tr = name.split(",")[1].strip()
+                name = "igemm_halo_bf16m512_kernel<%s, %s>" % (tr, "true" if srcs[0].dtype == ST_BF16 else "false")
     e0, e1 = _timer.bracket(name, flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")

@@ -881,3 +881,40 @@ def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample
             lib.mseg_igemm_set_persistent(1)
     assert rel_err(got[0], refn + base.float()) < 6e-3
     assert rel_err(got[0], got[1]) < 8e-3
+
+
+@pytest.mark.parametrize("N,H,W,act,per_sample", [(6, 128, 128, "relu", False), (13, 120, 80, "relu", True), (5, 150, 96, "mish", False)])
+def test_bf16_storage_512_pixel_tiles_concat_layers(eng, N, H, W, act, per_sample):
+    """128 -> 64 channel concat convolutions on bf16 tensors (two 64-channel sources) with enough pixels take 512-pixel tiles
+    (igemm_halo_bf16m512_kernel: four pixel tiles per weight stage): checked against torch on the rounded operands and
+    against the 128-pixel-tile kernel (mseg_igemm_set_persistent(0) switches both level-0 specialisations off); image
+    heights that are no multiple of the tile height, 16- and 32-pixel-wide tiles, per-sample tables, an expensive activation."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    Cin, Cout = 128, 64
+    g = torch.Generator().manual_seed(1700 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    nsc = (N, Cin) if per_sample else (Cin,)
+    scale, shift = rnd(g, *nsc) * 0.3 + 1.0, rnd(g, *nsc) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z16.float(), act, scale, shift, per_sample)), _bf(w), b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    c0 = Cin // 2
+    sl = (lambda t, a, b_: t[:, a:b_]) if per_sample else (lambda t, a, b_: t[a:b_])
+    nodes = []
+    for a, b_ in ((0, c0), (c0, Cin)):
+        n = _mk_node(eng, z16[:, a:b_].float(), act, sl(scale, a, b_).contiguous(), sl(shift, a, b_).contiguous(), per_sample)
+        n.z = n.z.to(torch.bfloat16)
+        nodes.append(n)
+    srcs = [n.src() for n in nodes]
+    outs = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_persistent(on) == 0
+        try:
+            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_persistent(1)
+    assert rel_err(nchw(outs[0]), ref) < (6e-3 if act != "mish" else 8e-3)
+    assert rel_err(outs[0], outs[1]) < 8e-3              # same operands, another fp32 accumulation order: at most one bf16 ulp
