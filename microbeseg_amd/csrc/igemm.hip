@@ -542,11 +542,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
 // TCONV in parity M-order with parity classes that are whole tiles; a tile's source rows < 2 GiB; the concat boundary C0 a
 // multiple of 32 (wave-uniform source selection).
 // TR: 0 = plain operand, 1 = none/ReLU + affine, 2 = any activation + affine.
-template <int BM, int BN, int TR, bool PER_SAMPLE>
+// SB: ONE LDS stage instead of two (an extra barrier per K-step, half the LDS: three workgroups per CU instead of two).
+// Chosen for launches of at most 8 K-steps (ConvTranspose as a 1x1 GEMM, the data gradients of the level-0 stride-2 /
+// transposed convolutions): such a tile is prologue, first fetch and epilogue more than K-loop, and what hides those is the
+// number of co-resident workgroups, not the overlap inside one.
+template <int BM, int BN, int TR, bool PER_SAMPLE, bool SB = false>
 __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
   using Cfg = IgemmCfg<BM, BN>;
   constexpr int STAGE = (BM + BN) * LDS_STRIDE;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float lds[(SB ? 1 : 2) * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -746,10 +750,16 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const MsegIgemm p) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
         }
     }
-    float* An = lds + (cur ^ 1) * STAGE;
-    commit(An, An + BM * LDS_STRIDE);
-    __syncthreads();
-    cur ^= 1;
+    if (SB) {
+      __syncthreads();                                   // every wave is done reading the only stage
+      commit(lds, lds + BM * LDS_STRIDE);
+      __syncthreads();
+    } else {
+      float* An = lds + (cur ^ 1) * STAGE;
+      commit(An, An + BM * LDS_STRIDE);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   igemm_epilogue<IgemmCfg<BM, BN>>(acc, m0, n0, wm, wn, lane, M);
 }
@@ -2314,8 +2324,15 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   }
   if (fast) {
     const int tr = plain ? 0 : (generic ? 2 : 1);
-#define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_) \
-  hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_>), grid, block, 0, st, p)
+    // K-steps of a tile: 32-channel chunks x live taps (a stride-2 transposed convolution in parity order has at most
+    // ceil(KH / 2) x ceil(KW / 2) live taps per tile)
+    const int live_taps = (p.mode == MSEG_MODE_TCONV && p.stride == 2) ? ((p.KH + 1) / 2) * ((p.KW + 1) / 2) : p.KH * p.KW;
+    const bool short_k = ((p.Cin + KC - 1) / KC) * live_taps <= 8;
+#define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_)                                                              \
+  do {                                                                                                    \
+    if (short_k) hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);        \
+  } while (0)
 #define MSEG_FAST_TILE(BM_, BN_)                                                          \
   do {                                                                                    \
     if (tr == 0) MSEG_FAST_LAUNCH(BM_, BN_, 0, false);                                    \

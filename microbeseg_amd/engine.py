@@ -140,7 +140,7 @@ def _halo_band_ok(srcs, Wi):
 
 
 def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False, parity_tiles=False, Ho=None,
-                       Wo=None):
+                       Wo=None, bf16_name=False):
     """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
     appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
     bn = 128 if Ngemm > 64 else 64
@@ -156,7 +156,11 @@ def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok
     if fast:
         tr = max(_tr_of(s) for s in srcs)
         tr = 0 if tr == 0 else (2 if generic else 1)
-        return "igemm_fast_kernel<128, %d, %d, %s>" % (bn, tr, "true" if (per_sample and tr) else "false")
+        # fp32 only: the single-LDS-stage form for launches of at most 8 K-steps (mirror of `short_k` in the launcher)
+        live = ((KH + 1) // 2) * ((KW + 1) // 2) if (mode == MODE_TCONV and stride == 2) else KH * KW
+        sb = ", true" if ((sum(s.C for s in srcs) + 31) // 32) * live <= 8 else ", false"
+        return "igemm_fast_kernel<128, %d, %d, %s%s>" % (bn, tr, "true" if (per_sample and tr) else "false",
+                                                        "" if bf16_name else sb)
     return "igemm_kernel<128, %d, %s, %s>" % (bn, "true" if per_sample else "false", "true" if generic else "false")
 
 
@@ -512,7 +516,8 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
                               halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
                                        and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
                                        and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
-                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0), Ho=Ho, Wo=Wo)
+                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0), Ho=Ho, Wo=Wo,
+                              bf16_name=bool(bf16))
     if bf16:
         name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
             "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")
