@@ -25,7 +25,7 @@
 
 // counters (int32 slots in workspace)
 enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_CONST_M = 7,
-       C_CONST_Q = 12, C_WORK_S = 16, C_WORK_L = 18, C_COUNT = 20 };   // C_WORK_*: two slots each
+       C_CONST_Q = 12, C_WORK_S = 16, C_WORK_L = 18, C_PART = 20, C_COUNT = 84 };   // C_WORK_*: two slots each; C_PART: 2 x 32
 
 struct PPWs {
   float* tmp; float* cs;
@@ -194,6 +194,22 @@ __global__ void pp_ccl_flatten_kernel(int32_t* __restrict__ L, size_t n) {
 }
 
 // ---- seed statistics, filtering, ordering ----------------------------------------------------------------------------
+// Per-pixel statistics of labelled components are atomics onto the component's root — hundreds of pixels per root.  Lanes
+// of a wavefront hold 64 consecutive pixels, so a component's pixels arrive in horizontal RUNS: only the first lane of a
+// run (same root as its left neighbour, same image row) issues the atomics, with the run's length.
+// Returns the run length for the run's first lane, 0 for every other lane.
+__device__ __forceinline__ int pp_run_length(int r, int x) {
+  const int lane = threadIdx.x & 63;
+  const int rp = __shfl_up(r, 1, 64);
+  const bool valid = r >= 0;
+  const bool head = valid && !(lane > 0 && rp == r && x > 0);
+  const unsigned long long cont = __ballot(valid && !head);          // lanes that continue their left neighbour's run
+  if (!head) return 0;
+  const unsigned long long m = lane == 63 ? 0ull : (cont >> (lane + 1));
+  return 1 + (int)__builtin_ctzll(~m);                                // trailing ones of m (m has at most 63 - lane bits)
+}
+
+
 __global__ void pp_fill_kernel(int32_t* __restrict__ a, int32_t v, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -205,17 +221,33 @@ __global__ void pp_seed_stats_kernel(const int32_t* __restrict__ L, int H, int W
   const size_t n = (size_t)H * W;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int r = i < n ? L[i] : -1;
-  if (r >= 0) {
-    atomicAdd(&area[r], 1);
-    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+  const int y = i < n ? (int)(i / W) : 0, x = i < n ? (int)(i - (size_t)y * W) : 0;
+  const int run = pp_run_length(r, x);
+  if (run > 0) {                                            // first pixel of a horizontal run: the run's smallest key
+    atomicAdd(&area[r], run);
     atomicMin(&ckey[r], col_major ? x * H + y : (int)i);
   }
-  // the two frame-wide counts: one atomic per wavefront instead of one per seed pixel
+  // the two frame-wide counts.  Atomics onto ONE address are served at ~10^8 per second: one per seed pixel, or even one
+  // per wavefront (30 k), is what this kernel's time consisted of.  A workgroup combines its four waves in LDS and adds to
+  // one of 32 partial counters; pp_seed_totals_kernel sums those.
+  __shared__ int sh_cnt[2];
+  if (threadIdx.x < 2) sh_cnt[threadIdx.x] = 0;
+  __syncthreads();
   const unsigned long long seeds = __ballot(r >= 0), roots = __ballot(r >= 0 && r == (int)i);
   if ((threadIdx.x & 63) == 0) {
-    if (seeds) atomicAdd(&counters[C_TOTAL], __popcll(seeds));
-    if (roots) atomicAdd(&counters[C_NCOMP], __popcll(roots));
+    if (seeds) atomicAdd(&sh_cnt[0], __popcll(seeds));
+    if (roots) atomicAdd(&sh_cnt[1], __popcll(roots));
   }
+  __syncthreads();
+  if (threadIdx.x < 2 && sh_cnt[threadIdx.x])
+    atomicAdd(&counters[C_PART + 32 * threadIdx.x + (blockIdx.x & 31)], sh_cnt[threadIdx.x]);
+}
+
+__global__ void pp_seed_totals_kernel(int32_t* __restrict__ counters) {
+  const int k = threadIdx.x >> 5, j = threadIdx.x & 31;           // 64 threads: [total | components] x 32 partials
+  int v = counters[C_PART + 32 * k + j];
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (j == 0) counters[k == 0 ? C_TOTAL : C_NCOMP] = v;
 }
 
 __device__ __forceinline__ bool pp_keep(int area, const int32_t* counters, int distance_rule) {
@@ -495,14 +527,15 @@ __global__ void pp_mcomp_stats_kernel(const int32_t* __restrict__ mlab, const in
                                       int32_t* __restrict__ bxmax, uint8_t* __restrict__ hasm) {
   const size_t n = (size_t)H * W;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int r = mlab[i];
-  if (r < 0) return;
-  const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-  atomicAdd(&carea[r], 1);
-  atomicMin(&bymin[r], y); atomicMax(&bymax[r], y);
-  atomicMin(&bxmin[r], x); atomicMax(&bxmax[r], x);
-  if (markers[i] != 0) hasm[r] = 1;
+  const int r = i < n ? mlab[i] : -1;
+  const int y = i < n ? (int)(i / W) : 0, x = i < n ? (int)(i - (size_t)y * W) : 0;
+  const int run = pp_run_length(r, x);                      // all 64 lanes take part
+  if (run > 0) {
+    atomicAdd(&carea[r], run);
+    atomicMin(&bymin[r], y); atomicMax(&bymax[r], y);
+    atomicMin(&bxmin[r], x); atomicMax(&bxmax[r], x + run - 1);
+  }
+  if (r >= 0 && markers[i] != 0) hasm[r] = 1;
 }
 
 // flag = 1 at roots of components that contain a marker; carea zeroed elsewhere (it becomes the heap-size scan input)
@@ -548,18 +581,18 @@ static int g_ppw_tile_s = PPW_TILE_S;
 static int g_ppw_tile_l = PPW_TILE_L;
 
 __device__ __forceinline__ unsigned ppw_wave_min(unsigned v) {
-#define PPW_STEP(CTRL, ROWS)                                                                             \
-  {                                                                                                      \
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xf, false);    \
-    v = o < v ? o : v;                                                                                   \
-  }
-  PPW_STEP(0xB1, 0xf)    // quad_perm [1,0,3,2]
-  PPW_STEP(0x4E, 0xf)    // quad_perm [2,3,0,1]
-  PPW_STEP(0x141, 0xf)   // row_half_mirror: 8 lanes
-  PPW_STEP(0x140, 0xf)   // row_mirror: 16 lanes
-  PPW_STEP(0x142, 0xa)   // row_bcast15 into rows 1, 3
-  PPW_STEP(0x143, 0xc)   // row_bcast31 into rows 2, 3
-#undef PPW_STEP
+  // min over the 64 lanes in six DPP steps, each ONE instruction (v_min_u32 with a DPP-permuted first operand, in place;
+  // the compiler's own lowering of update_dpp + min is a copy, a DPP move and the min per step, and the pop of the flood is
+  // a chain of dependent instructions).  s_nop 1: two wait states between a VALU write and its DPP read.
+  asm volatile(
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
@@ -649,10 +682,18 @@ __device__ __forceinline__ int ppw_component(
     // pop: smallest (value, age) over the cached column minima
     const unsigned hi = cnt > 0 ? (unsigned)(mk >> 32) : 0xffffffffu;
     const unsigned mh = ppw_wave_min(hi);
-    const unsigned lo = (cnt > 0 && hi == mh) ? (unsigned)mk : 0xffffffffu;
-    const unsigned ml = ppw_wave_min(lo);
+    const bool cand = cnt > 0 && hi == mh;
+    const unsigned long long cands = __ballot(cand);
+    unsigned ml;
+    int winner;
+    if ((cands & (cands - 1ull)) == 0ull) {                // one column holds the smallest value: no age comparison needed
+      winner = __builtin_amdgcn_readfirstlane(__ffsll((long long)cands) - 1);
+      ml = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mk, winner);
+    } else {                                               // equal values in several columns: the smallest age wins
+      ml = ppw_wave_min(cand ? (unsigned)mk : 0xffffffffu);
+      winner = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cand && (unsigned)mk == ml)) - 1);
+    }
     const unsigned long long k = ((unsigned long long)mh << 32) | ml;
-    const int winner = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(cnt > 0 && mk == k)) - 1);
     uint32_t e = 0; int lab = 0;
     if (lane == winner) {
       e = q_idx(mrow); lab = q_lab(mrow);
@@ -1161,6 +1202,7 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
   hipLaunchKernelGGL(pp_ccl_flatten_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, w.slab, n);
   hipLaunchKernelGGL(pp_seed_stats_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.slab, H, W, col_major,
                      w.area, w.ckey, w.counters);
+  hipLaunchKernelGGL(pp_seed_totals_kernel, dim3(1), dim3(64), 0, st, w.counters);
   hipLaunchKernelGGL(pp_seed_select_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.slab, n,
                      (const int32_t*)w.area, (const int32_t*)w.ckey, distance_rule, w.flag, w.counters);
   MSEG_LAUNCH_CHECK();
