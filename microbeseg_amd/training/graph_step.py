@@ -60,7 +60,9 @@ class GraphedTrainStep:
                 loss = self.step_fn(*batch)
             torch.cuda.current_stream().wait_stream(self.stream)
             return loss
-        if self.graph is not None and self._signature(batch) != self.shapes:
+        # the FIRST captured signature stays the one that is ever recorded: after invalidate() (a learning-rate step) the next
+        # call may well be the short last batch of an epoch, and recording that shape would leave every full batch eager
+        if self.shapes is not None and self._signature(batch) != self.shapes:
             return self.step_fn(*batch)              # e.g. the last, smaller batch of an epoch: eager
         if self.graph is None:
             self._capture(batch)

@@ -385,6 +385,12 @@ def test_graphed_train_step_equals_eager(precision, dev, request):
             losses.append(float(fn(*b).detach()))
             if i == 4:
                 losses.append(float(fn(*odd).detach()))
+            if i == 5:                                      # a learning-rate step forgets the recording; the very next batch is
+                if graphed:                                 # the short one: it must NOT become the recorded shape
+                    fn.invalidate()
+                losses.append(float(fn(*odd).detach()))
+        if graphed:
+            assert fn.graph is not None and fn.shapes[0][0][0] == 4, "the full batch must be the recorded shape again"
         return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
 
     l_e, sd_e = run(False)
