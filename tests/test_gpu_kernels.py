@@ -883,7 +883,7 @@ def test_bf16_storage_persistent_64_channel_layers(eng, N, H, W, act, per_sample
     assert rel_err(got[0], got[1]) < 8e-3
 
 
-@pytest.mark.parametrize("N,H,W,act,per_sample", [(6, 128, 128, "relu", False), (13, 120, 80, "relu", True), (5, 150, 96, "mish", False)])
+@pytest.mark.parametrize("N,H,W,act,per_sample", [(16, 128, 128, "relu", False), (26, 120, 80, "relu", True), (18, 150, 96, "mish", False)])
 def test_bf16_storage_512_pixel_tiles_concat_layers(eng, N, H, W, act, per_sample):
     """128 -> 64 channel concat convolutions on bf16 tensors (two 64-channel sources) with enough pixels take 512-pixel tiles
     (igemm_halo_bf16m512_kernel: four pixel tiles per weight stage): checked against torch on the rounded operands and
@@ -918,3 +918,6 @@ def test_bf16_storage_512_pixel_tiles_concat_layers(eng, N, H, W, act, per_sampl
             lib.mseg_igemm_set_persistent(1)
     assert rel_err(nchw(outs[0]), ref) < (6e-3 if act != "mish" else 8e-3)
     assert rel_err(outs[0], outs[1]) < 8e-3              # same operands, another fp32 accumulation order: at most one bf16 ulp
+    # the shapes are chosen so that the 512-pixel tiles are really taken (>= 2 tiles per compute unit)
+    tw = 32 if W % 32 == 0 else 16
+    assert N * (-(-H // (512 // tw))) * (W // tw) >= 2 * torch.cuda.get_device_properties(0).multi_processor_count
