@@ -609,6 +609,15 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad_reduce")
 
 
+_stats_epoch = 0
+
+
+def note_training_step():
+    """running BatchNorm statistics may have changed (a training forward ran, eagerly or inside a replayed graph)"""
+    global _stats_epoch
+    _stats_epoch += 1
+
+
 def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws):
     """Fill node.scale/shift (+mean/rstd) from a = act(z); BatchNorm eval mode uses the running statistics."""
     lib = _lib.load()
@@ -620,16 +629,26 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
         node.a = torch.empty_like(node.z)
     if norm == NORM["bn"]:
         node.ss = 0
-        node.scale = torch.empty(Cc, dtype=torch.float32, device=dev)
-        node.shift = torch.empty(Cc, dtype=torch.float32, device=dev)
         if not training:
-            check(lib.mseg_bn_eval_coeffs(_ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
-                                          BN_EPS, Cc, node.scale.data_ptr(), node.shift.data_ptr(), _stream()),
-                  "bn_eval_coeffs")
+            # eval-mode tables depend on the layer's parameters and running statistics only: computed once and kept on the
+            # running_mean buffer until one of the four tensors changes (a frame of a stack re-used 34 tiny launches)
+            key = (_stats_epoch,) + tuple((t.data_ptr(), t._version) if t is not None else None
+                                          for t in (gamma, beta, running_mean, running_var))
+            cached = running_mean.__dict__.get("_mseg_eval")
+            if cached is None or cached[0] != key:
+                scale = torch.empty(Cc, dtype=torch.float32, device=dev)
+                shift = torch.empty(Cc, dtype=torch.float32, device=dev)
+                check(lib.mseg_bn_eval_coeffs(_ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
+                                              BN_EPS, Cc, scale.data_ptr(), shift.data_ptr(), _stream()), "bn_eval_coeffs")
+                cached = (key, scale, shift)
+                running_mean.__dict__["_mseg_eval"] = cached
+            node.scale, node.shift = cached[1], cached[2]
             if expensive:
                 check(lib.mseg_activation(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, node.a.data_ptr(),
                                           _stream()), "activation")
             return
+        node.scale = torch.empty(Cc, dtype=torch.float32, device=dev)
+        node.shift = torch.empty(Cc, dtype=torch.float32, device=dev)
         node.mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         node.rstd = torch.empty(Cc, dtype=torch.float32, device=dev)
     else:
@@ -645,6 +664,11 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
                               node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
                               node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
                               _ptr(node.a), w.data_ptr(), _stream()), "norm_stats")
+    if running_mean is not None:
+        # the kernel updated the running statistics through raw pointers: tell torch, and start a new epoch of the eval-mode
+        # table cache above (a recorded step replayed by a hipGraph runs no Python: graph_step.py calls note_training_step)
+        torch.autograd.graph.increment_version((running_mean, running_var))
+        note_training_step()
 
 
 def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):

@@ -15,6 +15,8 @@ capture) — with real batches, so the trajectory is the eager one.
 """
 import torch
 
+from .. import engine
+
 
 class GraphedTrainStep:
     def __init__(self, step_fn, optimizer, warmup=2):
@@ -71,4 +73,5 @@ class GraphedTrainStep:
                 if s is not None:
                     s.copy_(b, non_blocking=True)
         self.graph.replay()
+        engine.note_training_step()                  # the replay updated running statistics without running any Python
         return self.static_loss

@@ -398,3 +398,44 @@ def test_graphed_train_step_equals_eager(precision, dev, request):
     assert l_e == l_g
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+def test_eval_tables_follow_training_and_loading(dev):
+    """Eval-mode BatchNorm tables are cached per layer: a training step (which updates the running statistics inside a
+    kernel), a state-dict load and an in-place edit of a buffer must each be seen by the next eval forward, and repeated eval
+    forwards must reuse the tables."""
+    from microbeseg_amd import engine
+    from microbeseg_amd.utils.unets import build_unet
+    from oracle import unet_ref
+    torch.manual_seed(3)
+    net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=(8, 16))
+    x = torch.rand(2, 1, 32, 32, device=dev) * 2 - 1
+
+    def eval_out():
+        net.eval()
+        with torch.no_grad():
+            return [t.clone() for t in net(x)]
+
+    def oracle_out():
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            return unet_ref.unet_forward(sd, x.cpu(), "DU", "relu", "bn", (8, 16), training=False)
+
+    a = eval_out()
+    epoch0 = engine._stats_epoch
+    b = eval_out()
+    assert engine._stats_epoch == epoch0 and all(torch.equal(u, v) for u, v in zip(a, b))
+    net.train()
+    net(x)[0].sum().backward()                               # running statistics move
+    c = eval_out()
+    assert not torch.equal(a[0], c[0])
+    for got, want in zip(c, oracle_out()):
+        assert (got.cpu() - want).abs().max() < 1e-4 * max(1.0, want.abs().max())
+    with torch.no_grad():                                    # in-place edit through torch
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(1.5)
+    d = eval_out()
+    assert not torch.equal(c[0], d[0])
+    for got, want in zip(d, oracle_out()):
+        assert (got.cpu() - want).abs().max() < 1e-4 * max(1.0, want.abs().max())
