@@ -105,6 +105,9 @@ size_t mseg_igemm_workspace_bytes(const MsegIgemm* p);
  * tile-per-workgroup kernel instead of the persistent one that keeps the layer's weights in LDS.  Same results either
  * way (the tests compare both).  Process-wide; default 1. */
 int mseg_igemm_set_persistent(int on);
+/* Test / ablation hook: on = 0 sends the 128-channel-tile bf16 layers back from 256-pixel to 128-pixel tiles
+ * (igemm_halo_bf16w4m_kernel -> igemm_halo_bf16w4_kernel).  Same results up to the fp32 accumulation order.  Default 1. */
+int mseg_igemm_set_wide_tiles(int on);
 
 /* weight gradient: G[t][mch][nch] = sum_p P[p][mch] * Q[gather(p, t)][nch], written to dst[(mch*Nch + nch)*T + t]
  * which *is* torch's layout for both Conv2d.weight (Cout,Cin,KH,KW) [P = dz, Q = conv input] and

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
     "mseg_igemm_workspace_bytes": (_SZ, [C.POINTER(MsegIgemm)]),
     "mseg_igemm_set_persistent": (_I, [_I]),
+    "mseg_igemm_set_wide_tiles": (_I, [_I]),
     "mseg_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

@@ -1524,6 +1524,269 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
   igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
 }
 
+// ---- 256-pixel tiles for the 128-channel-tile layers -----------------------------------------------------------------------
+// igemm_halo_bf16w4_kernel is bound by LDS traffic, not by the matrix pipe (counters: its LDS-array cycles equal its MFMA
+// cycles once the weight writes and the A-fragment conflicts of narrow tiles are counted).  Same four waves and the same 24
+// MFMAs per wave and stage, but a tile of 256 pixels x 128 channels: a wave owns 128 pixels x 64 channels (4 x 2 MFMA
+// blocks: 0.75 LDS reads per MFMA instead of 1.0) and a weight stage serves twice the pixels (half the weight bytes
+// written to LDS and fetched from L2 per MFMA).  To keep two workgroups per CU a stage holds HALF a 32-channel chunk of
+// the three taps of a kernel row (rows of 16 bf16 = 32 B at a 48-byte pitch: conflict-free 16-byte reads): six stages per
+// chunk, 64 KB of LDS.  Weights are fetched two stages ahead into two register sets like in the 128-pixel form (six
+// stages per chunk: the set of a stage is a compile-time choice without unrolling over two chunks).
+struct HaloCfg4M {
+  static constexpr int WN = 2, WM = 2;
+  static constexpr int TM = 128, TN = 64;
+  static constexpr int MB = 4, NB = 2;
+};
+#define HBM_BSTRIDE 24          // bf16 per weight row of a stage: 16 + 8 pad (48 B)
+
+template <int TR, bool S16>
+__global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4m_kernel(const MsegIgemm p, int tw_log2, int ksplit,
+                                                                    int chunks_per_split, int m_fastest) {
+  constexpr int BM = 256, BN = 128;
+  using Cfg = HaloCfg4M;
+  constexpr int HMAX = 340;                          // (8 + 2) x (32 + 2) = (32 + 2) x (8 + 2); 16 x 16 tiles: 18 x 18 = 324
+  constexpr int SQ = S16 ? 4 : 8;                    // staging threads per halo row (8 / 4 channels each)
+  constexpr int SROWS = 256 / SQ;                    // halo rows per staging pass
+  constexpr int HL = (HMAX + SROWS - 1) / SROWS;     // 16-byte loads per thread per chunk (11; 6 for bf16 sources)
+  constexpr int ASTAGE = HMAX * HB_STRIDE;
+  constexpr int BSTAGE = 3 * BN * HBM_BSTRIDE;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[ASTAGE + 2 * BSTAGE];
+  __shared__ __attribute__((aligned(16))) float tabs[64];   // norm-on-load tables of the chunk being committed: scale[32] | shift[32]
+  __bf16* const Abuf = lds;
+  __bf16* const Bbuf = lds + ASTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = tid / SQ, scol = tid % SQ;        // halo staging: SROWS rows x SQ channel groups per pass
+  const int brow = tid >> 1, bcol = tid & 1;         // weight staging: 128 rows x 2 groups of 8 channels per tap
+  const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
+  const int HROWS = (TH + 2) * HW2;
+  const int H = p.Hi, W = p.Wi;
+  const int M = p.NB * H * W;
+  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int ntiles_n = (p.Ngemm + BN - 1) / BN;
+  const int lid_all = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int ntiles_all = (int)gridDim.x / ksplit;
+  const int kz = lid_all / ntiles_all;
+  const int lid = lid_all - kz * ntiles_all;
+  const int ntiles_m = ntiles_all / ntiles_n;
+  const int tile_m = m_fastest ? lid % ntiles_m : lid / ntiles_n;
+  const int tile_n = m_fastest ? lid / ntiles_m : lid - tile_m * ntiles_n;
+  const int img = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - img * (tiles_x * tiles_y);
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * BN;
+  const int band0 = oy0 > 0 ? oy0 - 1 : 0;           // descriptors span the row band of this tile's halo (see the 128-pixel form)
+  const int band_rows = (oy0 + TH + 1 < H ? oy0 + TH + 1 : H) - band0;
+  const bool conv = p.mode == MSEG_MODE_CONV;
+
+  int hpix[HL];
+  unsigned hvalid = 0u;
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int hrow = srow + SROWS * j;
+    const int hy = hrow / HW2, hx = hrow - hy * HW2;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = (hrow < HROWS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+    hpix[j] = (iy - band0) * W + ix;
+    hvalid |= (unsigned)ok << j;
+  }
+  int abase[Cfg::MB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a) {
+    const int i = wm * Cfg::TM + a * 32 + li;
+    abase[a] = ((i >> tw_log2) * HW2 + (i & (TW - 1))) * HB_STRIDE + lh * 8;
+  }
+
+  f32x16 acc[Cfg::MB][Cfg::NB];
+#pragma unroll
+  for (int a = 0; a < Cfg::MB; ++a)
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = (p.Cin + KC - 1) / KC;
+  const int C0 = p.src[0].C;
+  const unsigned OOB = 0x80000000u;
+  const int C1 = p.nsrc > 1 ? p.src[1].C : p.src[0].C;
+  constexpr int ESZ = S16 ? 2 : 4;                   // bytes per source element
+  const char* const base0 = (const char*)p.src[0].ptr + ((size_t)img * H + band0) * W * p.src[0].C * ESZ;
+  const char* const base1 = (const char*)(p.nsrc > 1 ? p.src[1].ptr : p.src[0].ptr) + ((size_t)img * H + band0) * W * C1 * ESZ;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base0), 0,
+                                                                        band_rows * W * p.src[0].C * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base1), 0,
+                                                                        band_rows * W * C1 * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                        9 * p.Npad * p.Kpad * 2, 0x00020000);
+  const unsigned wvoff = ((unsigned)(n0 + brow) * (unsigned)p.Kpad + bcol * 8u) * 2u;
+
+  f32x4 rh[HL];                                      // 16 raw bytes: 4 fp32 or 8 bf16 source channels
+  float4 rt = make_float4(0.f, 0.f, 0.f, 0.f);       // threads 0..15: one float4 of the next chunk's tables (the accumulators
+  f32x4 rbA[3], rbB[3];                              // leave no room for every staging thread's own copy: they go through LDS)
+  unsigned hlive = 0u;
+  int ract = 0;
+  bool cur_s1 = false;
+
+  auto issue_halo = [&](int chunk) {
+    constexpr int CPT = S16 ? 8 : 4;                 // channels per staging thread
+    const int c = chunk * KC + scol * CPT;
+    cur_s1 = (p.nsrc > 1) && (chunk * KC >= C0);
+    const MsegSrc& s = cur_s1 ? p.src[1] : p.src[0];
+    const unsigned sCB = (unsigned)s.C * (unsigned)ESZ;                            // bytes per pixel
+    const unsigned soff = (unsigned)(chunk * KC - (cur_s1 ? C0 : 0)) * (unsigned)ESZ + scol * 16u;
+    hlive = (c < p.Cin) ? hvalid : 0u;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const bool ok = (hlive >> j) & 1u;
+      const unsigned vo = ok ? (unsigned)hpix[j] * sCB + soff : OOB;
+      rh[j] = cur_s1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, 0, 0))
+                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, vo, 0, 0));
+    }
+    if (TR != 0) {
+      ract = s.act;
+      if (tid < 16) {                                  // scale: threads 0..7, shift: threads 8..15, 4 channels each
+        const bool has_aff = s.scale != nullptr;
+        const float* tp = tid < 8 ? (has_aff ? s.scale : g_ident_scale) : (has_aff ? s.shift : g_ident_shift);
+        const int c4 = chunk * KC + (tid & 7) * 4;
+        const unsigned cl = (c4 < p.Cin) ? (unsigned)(cur_s1 ? c4 - C0 : c4) : 0u;
+        rt = *reinterpret_cast<const float4*>(tp + (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + cl);
+      }
+    }
+  };
+  // before the barrier that precedes commit_halo
+  auto publish_tables = [&]() {
+    if (TR != 0 && tid < 16) *reinterpret_cast<float4*>(tabs + tid * 4) = rt;
+  };
+
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo, float m) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = (v.x * sc.x + sh.x) * m; v.y = (v.y * sc.y + sh.y) * m;
+    v.z = (v.z * sc.z + sh.z) * m; v.w = (v.w * sc.w + sh.w) * m;
+    return v;
+  };
+
+  auto commit_halo = [&](__bf16* As) {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+    constexpr int CPT = S16 ? 8 : 4;
+    float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f), rsc2 = rsc, rsh2 = rsh;
+    if (TR != 0) {
+      rsc = *reinterpret_cast<const float4*>(tabs + scol * CPT);
+      rsh = *reinterpret_cast<const float4*>(tabs + 32 + scol * CPT);
+      if (S16) {
+        rsc2 = *reinterpret_cast<const float4*>(tabs + scol * CPT + 4);
+        rsh2 = *reinterpret_cast<const float4*>(tabs + 32 + scol * CPT + 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      const int hrow = srow + SROWS * j;
+      if (hrow < HMAX) {
+        const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
+        if (S16) {
+          const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
+          if (TR == 0) {                             // plain bf16 operand: already in LDS format
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else {
+            const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
+            const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
+            const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = make_uint4(pa.x, pa.y, pb.x, pb.y);
+          }
+        } else {
+          float4 v = make_float4(rh[j][0], rh[j][1], rh[j][2], rh[j][3]);
+          if (TR != 0) v = xform4(v, rsc, rsh, lo, m);
+          bf16x4 h;
+          h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+          *reinterpret_cast<bf16x4*>(As + hrow * HB_STRIDE + scol * 4) = h;
+        }
+      }
+    }
+  };
+
+  // stage = (chunk, kernel row ky, K half kh): weights of 3 taps x [BN][16] bf16
+  auto issue_b = [&](f32x4 (&rb)[3], int chunk, int ky, int kh) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned wso = ((unsigned)(ky * 3 + kx) * (unsigned)p.Npad * (unsigned)p.Kpad + (unsigned)chunk * KC +
+                            (unsigned)kh * 16u) * 2u;
+      rb[kx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, wso, 0));
+    }
+  };
+  auto commit_b = [&](const f32x4 (&rb)[3], __bf16* Bs) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      *reinterpret_cast<f32x4*>(Bs + (kx * BN + brow) * HBM_BSTRIDE + bcol * 8) = rb[kx];
+  };
+
+  const int c_begin = kz * chunks_per_split;
+  const int c_end = (c_begin + chunks_per_split < nchunks) ? c_begin + chunks_per_split : nchunks;
+  // stage index within a chunk: st = ky * 2 + kh (0..5); stages past the end re-read the last one (branch-free, harmless)
+  auto stage_at = [&](int chunk, int st, int ahead, int& c2, int& s2) {
+    s2 = st + ahead; c2 = chunk;
+    if (s2 >= 6) { s2 -= 6; c2 += 1; }
+    if (c2 >= c_end) { c2 = c_end - 1; s2 = 5; }
+  };
+  int bsel = 0;
+  {
+    int c1, s1;
+    issue_halo(c_begin);
+    issue_b(rbA, c_begin, 0, 0);
+    stage_at(c_begin, 0, 1, c1, s1);
+    issue_b(rbB, c1, s1 >> 1, s1 & 1);
+    publish_tables();
+    __syncthreads();
+    commit_halo(Abuf);
+    commit_b(rbA, Bbuf);
+    __syncthreads();
+  }
+#define MSEG_HBM_STAGE(FREE_, HELD_, chunk_, st_)                                                                  \
+  {                                                                                                                \
+    const int chunk = (chunk_);                                                                                    \
+    constexpr int st = (st_);                                                                                      \
+    constexpr int ky = st >> 1, kh = st & 1;                                                                       \
+    const bool more_chunks = chunk + 1 < c_end;                                                                    \
+    if (st == 0 && more_chunks) issue_halo(chunk + 1);                                                             \
+    int c2, s2;                                                                                                    \
+    stage_at(chunk, st, 2, c2, s2);                                                                                \
+    issue_b(FREE_, c2, s2 >> 1, s2 & 1);                                                                           \
+    const __bf16* As = Abuf;                                                                                       \
+    const __bf16* Bs = Bbuf + bsel * BSTAGE;                                                                       \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                             \
+      const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * HB_STRIDE;                            \
+      bf16x8 bf[Cfg::NB];                                                                                          \
+      _Pragma("unroll") for (int b = 0; b < Cfg::NB; ++b)                                                          \
+        bf[b] = *reinterpret_cast<const bf16x8*>(Bs + (kx * BN + wn * Cfg::TN + b * 32 + li) * HBM_BSTRIDE + lh * 8); \
+      _Pragma("unroll") for (int a = 0; a < Cfg::MB; ++a) {                                                        \
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + abase[a] + toff + kh * 16);                        \
+        _Pragma("unroll") for (int b = 0; b < Cfg::NB; ++b)                                                        \
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[b], acc[a][b], 0, 0, 0);                      \
+      }                                                                                                            \
+    }                                                                                                              \
+    commit_b(HELD_, Bbuf + (bsel ^ 1) * BSTAGE);                                                                   \
+    if (st == 5 && more_chunks) {                                                                                  \
+      publish_tables();                                                                                            \
+      __syncthreads();                                                                                             \
+      commit_halo(Abuf);                                                                                           \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    bsel ^= 1;                                                                                                     \
+  }
+  for (int chunk0 = c_begin; chunk0 < c_end; ++chunk0) {
+    MSEG_HBM_STAGE(rbA, rbB, chunk0, 0)
+    MSEG_HBM_STAGE(rbB, rbA, chunk0, 1)
+    MSEG_HBM_STAGE(rbA, rbB, chunk0, 2)
+    MSEG_HBM_STAGE(rbB, rbA, chunk0, 3)
+    MSEG_HBM_STAGE(rbA, rbB, chunk0, 4)
+    MSEG_HBM_STAGE(rbB, rbA, chunk0, 5)
+  }
+#undef MSEG_HBM_STAGE
+  igemm_epilogue<Cfg>(acc, 0, n0, wm, wn, lane, M * ksplit, tw_log2, img + kz * p.NB, oy0, ox0);
+}
+
 // ---- persistent bf16 kernel for the 64 -> 64 channel layers of level 0 ------------------------------------------------------
 // Level 0 has the most pixels and the fewest channels: 3 x 3 x 64 x 64 is 241 GFLOP per launch at 32 x 320 x 320 (0.1 ms
 // at the bf16 matrix peak) against 0.84 GB of bf16 tensors in and out (0.17 ms at 5 TB/s) — an HBM-bound layer.  The
@@ -2115,11 +2378,19 @@ static int c64p_workgroups() {
 
 // 512-pixel tiles (igemm_halo_bf16m512_kernel): tile count, or 0 when more than a fifth of the tile rows would fall below
 // the image
-static long long halo512_tiles(const MsegIgemm& p, int tw_log2) {
-  const int TH = 512 >> tw_log2;
+static long long halo_big_tiles(const MsegIgemm& p, int tw_log2, int BMv) {
+  const int TH = BMv >> tw_log2;
   const long long rows = (long long)((p.Hi + TH - 1) / TH) * TH;
   if ((long long)p.Hi * 5 < rows * 4) return 0;
   return (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
+}
+static long long halo512_tiles(const MsegIgemm& p, int tw_log2) { return halo_big_tiles(p, tw_log2, 512); }
+
+static int g_w4m_on = 1;
+// Test / ablation hook: 0 sends the 128-channel-tile bf16 layers back to 128-pixel tiles.  Process-wide.
+extern "C" int mseg_igemm_set_wide_tiles(int on) {
+  g_w4m_on = on ? 1 : 0;
+  return MSEG_OK;
 }
 
 static bool halo_geometry(const MsegIgemm& p, int BNv, int* tw_log2_out, long long* htiles_out) {
@@ -2282,6 +2553,15 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   } while (0)
       if (tr == 0) MSEG_HALO512(0); else if (tr == 1) MSEG_HALO512(1); else MSEG_HALO512(2);
 #undef MSEG_HALO512
+    } else if (p.precision == MSEG_PREC_BF16 && wide && s16 && g_w4m_on && ks == 1 && tw_log2 >= 3 &&
+               halo_big_tiles(p, tw_log2, 256) * ((p.Ngemm + 127) / 128) >= 2 * (long long)c64p_workgroups()) {
+      // 128-channel tiles on enough pixels: 256-pixel tiles (fewer LDS reads and weight bytes per MFMA)
+      const dim3 mgrid((unsigned)(halo_big_tiles(p, tw_log2, 256) * ((p.Ngemm + 127) / 128)));
+      // (bf16 tensors only: with fp32 sources the 11 staging loads per thread do not fit beside 128 accumulator registers)
+#define MSEG_HALOW4M(TR_) \
+  hipLaunchKernelGGL((igemm_halo_bf16w4m_kernel<TR_, true>), mgrid, dim3(256), 0, st, q, tw_log2, 1, cps, m_fastest)
+      if (tr == 0) MSEG_HALOW4M(0); else if (tr == 1) MSEG_HALOW4M(1); else MSEG_HALOW4M(2);
+#undef MSEG_HALOW4M
     } else if (p.precision == MSEG_PREC_BF16) {
       if (wide) { if (tr == 0) MSEG_HALO16W4(0); else if (tr == 1) MSEG_HALO16W4(1); else MSEG_HALO16W4(2); }
       else      { if (tr == 0) MSEG_HALO16(64, 0); else if (tr == 1) MSEG_HALO16(64, 1); else MSEG_HALO16(64, 2); }

@@ -534,6 +534,14 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             if tiles >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
                 tr = name.split(",")[1].strip()
                 name = "igemm_c64p_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
+        elif name.startswith("igemm_halo_bf16w4_kernel<") and srcs[0].dtype == ST_BF16 and need == 0 and Wi % 8 == 0:
+            # 128-channel tiles on bf16 tensors with enough pixels: 256-pixel tiles (mirror of the launcher's rule)
+            tw = 32 if Wi % 32 == 0 else (16 if Wi % 16 == 0 else 8)
+            th = 256 // tw
+            rows = (Hi + th - 1) // th * th
+            tiles = NB * (rows // th) * (Wi // tw) * ((Ngemm + 127) // 128)
+            if Hi * 5 >= rows * 4 and tiles >= 2 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+                name = name.replace("igemm_halo_bf16w4_kernel<", "igemm_halo_bf16w4m_kernel<")
         elif name.startswith("igemm_halo_bf16_kernel<64") and p.Cin >= 128 and need == 0 and Wi % 16 == 0:
             # few output channels, many input channels (the 128 -> 64 concat convolutions): 512-pixel tiles
             tw = 32 if Wi % 32 == 0 else 16

@@ -921,3 +921,64 @@ def test_bf16_storage_512_pixel_tiles_concat_layers(eng, N, H, W, act, per_sampl
     # the shapes are chosen so that the 512-pixel tiles are really taken (>= 2 tiles per compute unit)
     tw = 32 if W % 32 == 0 else 16
     assert N * (-(-H // (512 // tw))) * (W // tw) >= 2 * torch.cuda.get_device_properties(0).multi_processor_count
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act,per_sample,two_src", [
+    (16, 128, 128, 128, 128, "relu", False, False), (12, 256, 256, 80, 80, "relu", True, True),
+    (16, 128, 256, 72, 64, "mish", False, False), (26, 192, 256, 64, 40, "none", False, False)])
+def test_bf16_storage_256_pixel_tiles(eng, N, Cin, Cout, H, W, act, per_sample, two_src):
+    """128-channel-tile layers on bf16 tensors with enough pixels take 256-pixel tiles (igemm_halo_bf16w4m_kernel: half-chunk
+    weight stages, tables through LDS): forward with norm-on-load sources (one and two sources, per-channel and per-sample
+    tables, cheap and expensive activations) and data gradient with a plain operand, 32- / 16- / 8-pixel-wide tiles, image
+    heights that are no multiple of the tile height; against torch on the rounded operands and against the 128-pixel-tile
+    kernel (mseg_igemm_set_wide_tiles(0))."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    tw = next(t for t in (32, 16, 8) if W % t == 0)      # the shapes are chosen so that the 256-pixel tiles are really taken
+    th = 256 // tw
+    assert N * (-(-H // th)) * (W // tw) * (-(-Cout // 128)) >= 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    assert H * 5 >= (-(-H // th)) * th * 4
+    g = torch.Generator().manual_seed(2100 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    nsc = (N, Cin) if per_sample else (Cin,)
+    scale, shift = rnd(g, *nsc) * 0.3 + 1.0, rnd(g, *nsc) * 0.1
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z16.float(), act, scale, shift, per_sample)), _bf(w), b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    sl = (lambda t, a, b_: t[:, a:b_]) if per_sample else (lambda t, a, b_: t[a:b_])
+    cuts = ((0, Cin // 2), (Cin // 2, Cin)) if two_src else ((0, Cin),)
+    nodes = []
+    for a, b_ in cuts:
+        n = _mk_node(eng, z16[:, a:b_].float(), act, sl(scale, a, b_).contiguous(), sl(shift, a, b_).contiguous(), per_sample)
+        n.z = n.z.to(torch.bfloat16)
+        nodes.append(n)
+    srcs = [n.src() for n in nodes]
+    outs = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_wide_tiles(on) == 0
+        try:
+            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_wide_tiles(1)
+    assert rel_err(nchw(outs[0]), ref) < (6e-3 if act != "mish" else 8e-3)
+    assert rel_err(outs[0], outs[1]) < 8e-3              # same operands, another fp32 accumulation order: at most one bf16 ulp
+    # data gradient: plain bf16 operand, accumulate into a bf16 destination
+    gy16 = _b16(rnd(g, N, Cout, H, W))
+    refn = nhwc(F.conv_transpose2d(gy16.float(), _bf(w), None, padding=1))
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    base = _b16(rnd(g, N, H, W, Cin))
+    dz = nhwc(gy16).cuda()
+    got = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_wide_tiles(on) == 0
+        try:
+            d0 = base.clone().cuda()
+            eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, Cin, acc0=1,
+                      precision="bf16")
+            got.append(d0.float().cpu())
+        finally:
+            lib.mseg_igemm_set_wide_tiles(1)
+    assert rel_err(got[0], refn + base.float()) < 6e-3
+    assert rel_err(got[0], got[1]) < 8e-3
