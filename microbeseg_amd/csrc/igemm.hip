@@ -1484,6 +1484,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
     issue_b(FREE_, c2, k2);                                                                                        \
     const __bf16* As = Abuf;                                                                                       \
     const __bf16* Bs = Bbuf + bsel * BSTAGE;                                                                       \
+    __builtin_amdgcn_iglp_opt(1);                                                                                  \
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                             \
       const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * HB_STRIDE;                            \
       _Pragma("unroll") for (int kk = 0; kk < KC / 16; ++kk) {                                                     \
@@ -1755,6 +1756,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4m_kernel(const MsegIg
     issue_b(FREE_, c2, s2 >> 1, s2 & 1);                                                                           \
     const __bf16* As = Abuf;                                                                                       \
     const __bf16* Bs = Bbuf + bsel * BSTAGE;                                                                       \
+    __builtin_amdgcn_iglp_opt(1);                                                                                  \
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                             \
       const int toff = ((conv ? ky : 2 - ky) * HW2 + (conv ? kx : 2 - kx)) * HB_STRIDE;                            \
       bf16x8 bf[Cfg::NB];                                                                                          \
