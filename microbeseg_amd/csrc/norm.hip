@@ -245,6 +245,9 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   if (norm == MSEG_NORM_BN) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
       double s = 0.0, q = 0.0;
+      // (unrolled: the loads of 8 samples are in flight together; rolled, this tiny kernel was 32 dependent memory round
+      // trips = 11 us, 114 such launches per step; the order of the additions is unchanged)
+#pragma unroll 8
       for (int n = 0; n < g.N; ++n) { s += S[(size_t)n * g.C + c]; q += Q[(size_t)n * g.C + c]; }
       const double cnt = (double)g.N * g.HW;
       const double mean = s / cnt;
@@ -302,6 +305,7 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   if (norm == MSEG_NORM_BN) {
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
       double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
       for (int n = 0; n < g.N; ++n) { s1 += S1[(size_t)n * g.C + c]; s2 += S2[(size_t)n * g.C + c]; }
       const double cnt = (double)g.N * g.HW;
       const double mu = mean[c], r = rstd[c], ga = gamma ? (double)gamma[c] : 1.0;
@@ -358,6 +362,7 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom
 __global__ void norm_colsum_kernel(const double* __restrict__ nc, NormGeom g, float* __restrict__ out) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
     double s = 0.0;
+#pragma unroll 8
     for (int n = 0; n < g.N; ++n) s += nc[(size_t)n * g.C + c];
     out[c] = (float)s;
   }
