@@ -801,7 +801,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
         norm_stats(node, spec.norm, nm.weight.detach(), nm.bias.detach(), nm.running_mean, nm.running_var,
                    training, ws)
         if training:
-            nm.num_batches_tracked.add_(1)
+            _nbt_pending.append(nm.num_batches_tracked)    # all layers' counters advance in ONE launch (end of forward)
     elif spec.norm == NORM["gn"]:
         norm_stats(node, spec.norm, nm.weight.detach(), nm.bias.detach(), None, None, training, ws)
     else:
@@ -830,9 +830,13 @@ def _run_maxpool(src_node, tape):
     return node
 
 
+_nbt_pending = []      # BatchNorm num_batches_tracked tensors of the training forward in progress
+
+
 def forward(spec, x, training, keep_tape, ws):
     """x: (N, ch_in, H, W) fp32 CUDA tensor.  Returns (list of NCHW outputs, Tape|None)."""
     lib = _lib.load()
+    del _nbt_pending[:]
     N, cin, H, W = x.shape
     nlev = len(spec.enc)
     div = 2 ** (nlev - 1)
@@ -878,6 +882,9 @@ def forward(spec, x, training, keep_tape, ws):
         outs.append(out)
         if tape is not None:
             tape.heads.append((d["head"], cur))
+    if _nbt_pending:
+        torch._foreach_add_(_nbt_pending, 1)
+        del _nbt_pending[:]
     return outs, tape
 
 
