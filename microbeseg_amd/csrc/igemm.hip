@@ -2083,6 +2083,185 @@ __global__ __launch_bounds__(512, 1) void igemm_c64p_bf16_kernel(const MsegIgemm
   }
 }
 
+// ---- persistent bf16 kernel for the level-0 ConvTranspose2d(128 -> 64, 2, stride 2) ------------------------------------------
+// As a GEMM this layer is M = input pixels, K = 128, N = 4 x 64 (the four output positions of a pixel), i.e. 66 kFLOP per
+// 768 bytes moved: HBM-bound like the 64 -> 64 convolutions, and like them it ran at a third of that bound on the
+// tile-per-workgroup gather kernel (four K-steps per tile: prologue, first fetch and scatter epilogue with nothing to
+// overlap them).  Same treatment as igemm_c64p_bf16_kernel: the 64 KB of weights stay in LDS, two groups of four waves walk
+// their own 128-pixel tiles out of step (LDS-counter barriers), rows fetched one tile ahead, LDS-only synchronisation.
+// No halo here: a tile is 128 consecutive pixels of the NHWC tensor (one contiguous 32 KB read); a wave owns 64 pixels x
+// 128 of the 256 GEMM columns; 32-pixel blocks stay inside an image row (W % 32 == 0), so the scatter is affine per block.
+struct CtpCfg {
+  static constexpr int MB = 2, NB = 4;               // per wave: 64 pixels x 128 columns
+};
+#define CTP_STRIDE 136          // bf16 per LDS row: 128 channels + 8 pad (272 B: conflict-free 16-byte reads of consecutive rows)
+
+template <int TR, bool D16>
+__global__ __launch_bounds__(512, 1) void igemm_ctp_bf16_kernel(const MsegIgemm p, int ntiles) {
+  constexpr int HL = 8;                               // staging passes of a group: 128 rows x 16 threads over 256 threads
+  constexpr int NE = D16 ? 8 : 16;                    // stores per lane and 32 x 32 block (bf16: channel pairs)
+  __shared__ __attribute__((aligned(16))) __bf16 lds[256 * CTP_STRIDE + 2 * 128 * CTP_STRIDE];
+  __shared__ unsigned gcount[2];
+  __bf16* const Wl = lds;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int gtid = tid & 255;
+  __bf16* const Al = lds + 256 * CTP_STRIDE + grp * 128 * CTP_STRIDE;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = gtid >> 4, scol = gtid & 15;       // staging: 16 rows x 16 groups of 8 channels per pass
+  const int H = p.Hi, W = p.Wi, HW = H * W;
+  const int Cq = p.Cq;                                // 64 output channels
+  const MsegSrc& s = p.src[0];
+  const __bf16* const srcp = reinterpret_cast<const __bf16*>(s.ptr);
+
+  // weights: [256 GEMM columns][128 k] bf16, resident for the whole launch
+  {
+    const __bf16* const wp = reinterpret_cast<const __bf16*>(p.w);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 512 * i;                   // 256 rows x 16 column groups = 4096
+      const int row = idx >> 4, c8 = idx & 15;
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + (size_t)row * p.Kpad + c8 * 8);
+      *reinterpret_cast<uint4*>(Wl + row * CTP_STRIDE + c8 * 8) = v;
+    }
+    if (tid < 2) gcount[tid] = 0u;
+  }
+  __syncthreads();                                     // the only workgroup-wide barrier
+
+  // output side, launch-invariant per lane: this lane's channel, its bias, the offsets of its rows inside a 32-pixel block
+  // (consecutive input pixels of one image row are 2 output pixels = 2 * Cq elements apart)
+  const bool odd = li & 1;
+  const int co = li;                                   // + 32 * (b & 1): two 32-column blocks per output position
+  float bias[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) bias[h] = p.bias ? p.bias[32 * h + co] : 0.f;
+  int eoff[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int r = D16 ? 2 * e + (odd ? 1 : 0) : e;
+    eoff[e] = ((r & 3) + 8 * (r >> 2) + 4 * lh) * 2 * Cq;
+  }
+
+  uint4 rh[HL];
+  float4 tsc[2], tsh[2];
+  int ract = 0;
+
+  auto issue_rows = [&](int t) {
+    const __bf16* const tb = srcp + (size_t)t * 128 * 128 + scol * 8;          // tile t: pixels 128 t .. 128 t + 127
+#pragma unroll
+    for (int j = 0; j < HL; ++j) rh[j] = *reinterpret_cast<const uint4*>(tb + (size_t)(srow + 16 * j) * 128);
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const int img = (int)(((long long)t * 128) / HW);                         // a tile never spans two images (HW % 128 == 0)
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + scol * 8;
+      tsc[0] = *reinterpret_cast<const float4*>(scp + o); tsc[1] = *reinterpret_cast<const float4*>(scp + o + 4);
+      tsh[0] = *reinterpret_cast<const float4*>(shp + o); tsh[1] = *reinterpret_cast<const float4*>(shp + o + 4);
+    }
+  };
+  auto xform4 = [&](float4 v, const float4& sc, const float4& sh, float lo) -> float4 {
+    if (TR == 2) v = act_fwd4(v, ract);
+    else { v.x = clamp_lo(v.x, lo); v.y = clamp_lo(v.y, lo); v.z = clamp_lo(v.z, lo); v.w = clamp_lo(v.w, lo); }
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    return v;
+  };
+  auto commit_rows = [&]() {
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      uint4 v = rh[j];
+      if (TR != 0) {
+        const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
+        const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
+        const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+        v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+      }
+      *reinterpret_cast<uint4*>(Al + (srow + 16 * j) * CTP_STRIDE + scol * 8) = v;
+    }
+  };
+
+  // scatter of one finished tile: GEMM column n = (a * 2 + b) * Cq + co goes to output pixel (2 y + a, 2 x + b), channel co
+  auto store_tile = [&](f32x16 (&acc)[CtpCfg::MB][CtpCfg::NB], int t) {
+#pragma unroll
+    for (int mb = 0; mb < CtpCfg::MB; ++mb) {
+      const int p0 = t * 128 + wm * 64 + mb * 32;       // first input pixel of this 32-row block (wave-uniform)
+      const int img = p0 / HW;
+      const int rem = p0 - img * HW;
+      const int y = rem / W, x0 = rem - y * W;
+#pragma unroll
+      for (int nb = 0; nb < CtpCfg::NB; ++nb) {
+        const int ab = wn * 2 + (nb >> 1);              // output position of this 32-column block
+        const long long base = ((((long long)img * 2 * H + 2 * y + (ab >> 1)) * 2 * W) + 2 * x0 + (ab & 1)) * Cq +
+                               32 * (nb & 1) + co;
+        const float bv = bias[nb & 1];
+        if (D16) {
+          __bf16* const d = reinterpret_cast<__bf16*>(p.dst0) + base - (odd ? 1 : 0);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const float mine_e = acc[mb][nb][2 * e] + bv, mine_o = acc[mb][nb][2 * e + 1] + bv;
+            const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+            // the neighbour lane holds the adjacent channel, whose bias differs: it was added on the giving side
+            *reinterpret_cast<unsigned*>(d + eoff[e]) = pack_bf16x2(odd ? got : keep, odd ? keep : got);
+          }
+        } else {
+          float* const d = reinterpret_cast<float*>(p.dst0) + base;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) d[eoff[e]] = acc[mb][nb][e] + bv;
+        }
+      }
+    }
+  };
+
+  const int stride = 2 * (int)gridDim.x;
+  int t = 2 * (int)xcd_logical_id(blockIdx.x, gridDim.x) + grp;
+  unsigned gb_target = 0u;
+  unsigned* const gcnt = &gcount[grp];
+  if (t < ntiles) {
+    issue_rows(t);
+    commit_rows();
+    if (t + stride < ntiles) issue_rows(t + stride);
+    c64_group_barrier(gcnt, gb_target);
+  }
+  const int a_off = (wm * 64 + li) * CTP_STRIDE + lh * 8;
+  const int b_off = (wn * 128 + li) * CTP_STRIDE + lh * 8;
+  for (; t < ntiles; t += stride) {
+    const int next = t + stride;
+    f32x16 acc[CtpCfg::MB][CtpCfg::NB];
+#pragma unroll
+    for (int mb = 0; mb < CtpCfg::MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < CtpCfg::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      bf16x8 af[CtpCfg::MB];
+#pragma unroll
+      for (int mb = 0; mb < CtpCfg::MB; ++mb)
+        af[mb] = *reinterpret_cast<const bf16x8*>(Al + a_off + mb * 32 * CTP_STRIDE + kk * 16);
+#pragma unroll
+      for (int nb = 0; nb < CtpCfg::NB; ++nb) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Wl + b_off + nb * 32 * CTP_STRIDE + kk * 16);
+#pragma unroll
+        for (int mb = 0; mb < CtpCfg::MB; ++mb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bf, acc[mb][nb], 0, 0, 0);
+      }
+    }
+    c64_group_barrier(gcnt, gb_target);                 // the group is done reading this tile's rows
+    if (next < ntiles) {
+      commit_rows();
+      if (next + stride < ntiles) issue_rows(next + stride);
+    }
+    store_tile(acc, t);
+    c64_group_barrier(gcnt, gb_target);                 // the next tile is in LDS
+  }
+}
+
 // ---- bf16 variant of the gather kernel (stride-2 convolutions, ConvTranspose as a 1x1 GEMM, their data gradients) ----
 // igemm_fast_kernel with bf16 matrix-core inputs: same per-row offsets / tap masks / live-tap list and epilogue; the staged
 // source pixels are rounded to bf16 after the norm-on-load transform, the weights arrive as bf16, LDS rows are 32 bf16 +
@@ -2582,6 +2761,24 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
                          p.split < p.Ngemm ? p.split : p.Ngemm, p.dst_dtype == MSEG_ST_BF16 ? 1 : 0);
       MSEG_LAUNCH_CHECK();
     }
+    return MSEG_OK;
+  }
+  if (p.precision == MSEG_PREC_BF16 && s16 && g_c64p_on && p.epi == MSEG_EPI_SCATTER2X2 && p.KH == 1 && p.KW == 1 &&
+      p.stride == 1 && p.pad == 0 && p.mode == MSEG_MODE_CONV && p.nsrc == 1 && p.Cin == 128 && p.Kpad == 128 &&
+      p.Cq == 64 && p.Ngemm == 256 && !p.acc0 && (p.Wi % 32) == 0 && (((long long)p.Hi * p.Wi) % 128) == 0 &&
+      M / 128 >= 4 * (long long)c64p_workgroups()) {
+    // ConvTranspose2d(128 -> 64, 2, stride 2) on bf16 tensors (level 0): persistent workgroups with resident weights
+    const int tr = plain ? 0 : (generic ? 2 : 1);
+    const dim3 pgrid((unsigned)c64p_workgroups());
+    const int nt = (int)(M / 128);
+#define MSEG_CTP(TR_)                                                                                                \
+  do {                                                                                                               \
+    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctp_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
+    else hipLaunchKernelGGL((igemm_ctp_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                     \
+  } while (0)
+    if (tr == 0) MSEG_CTP(0); else if (tr == 1) MSEG_CTP(1); else MSEG_CTP(2);
+#undef MSEG_CTP
+    MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }
   if (p.precision == MSEG_PREC_BF16) {                             // bf16 inputs: the halo and the gather kernel only

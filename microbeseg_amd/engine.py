@@ -534,6 +534,12 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             if tiles >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
                 tr = name.split(",")[1].strip()
                 name = "igemm_c64p_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
+        elif epi == EPI_SCATTER2X2 and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 128 and w.Kpad == 128 and \
+                Cq == 64 and Ngemm == 256 and not acc0 and Wi % 32 == 0 and (Hi * Wi) % 128 == 0 and \
+                NB * Hi * Wi // 128 >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+            # ConvTranspose2d(128 -> 64) of level 0 on bf16 tensors: the persistent kernel (mirror of the launcher's rule)
+            tr = name.split(",")[2].strip()
+            name = "igemm_ctp_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
         elif name.startswith("igemm_halo_bf16w4_kernel<") and srcs[0].dtype == ST_BF16 and need == 0 and Wi % 8 == 0:
             # 128-channel tiles on bf16 tensors with enough pixels: 256-pixel tiles (mirror of the launcher's rule)
             tw = 32 if Wi % 32 == 0 else (16 if Wi % 16 == 0 else 8)
