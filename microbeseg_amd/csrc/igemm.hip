@@ -2262,6 +2262,148 @@ __global__ __launch_bounds__(512, 1) void igemm_ctp_bf16_kernel(const MsegIgemm 
   }
 }
 
+// ---- ... and for its data gradient: Conv2d(64 -> 128, 2, stride 2) over dz ------------------------------------------------
+// dx[p][ci] = sum over the 2 x 2 output positions (a, b) and co of dz[2 p + (a, b)][co] * W[ci][co][a][b]: M = low-resolution
+// pixels, K = 4 taps x 64 channels, N = 128.  Resident weights (4 x 128 rows of 64 k), tiles of 64 low-resolution pixels =
+// two 32-pixel blocks inside an image row, each staged with all four taps ([64 rows][256 k], 528-byte pitch): the two source
+// pixels of a row pair are adjacent in memory (256 contiguous bytes per pixel and image row).  A wave owns 32 pixels x 64
+// columns.  Plain operand (dz), one destination, no accumulation — anything else stays on the gather kernel.
+#define CTD_ASTRIDE 264         // bf16 per LDS row of the tile: 256 k + 8 pad (528 B)
+
+template <bool D16>
+__global__ __launch_bounds__(512, 1) void igemm_ctd_bf16_kernel(const MsegIgemm p, int ntiles) {
+  constexpr int HL = 8;                               // staging passes of a group: 64 rows x 4 taps x 8 column groups / 256
+  constexpr int NE = D16 ? 8 : 16;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * 128 * C64_STRIDE + 2 * 64 * CTD_ASTRIDE];
+  __shared__ unsigned gcount[2];
+  __bf16* const Wl = lds;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int gtid = tid & 255;
+  __bf16* const Al = lds + 4 * 128 * C64_STRIDE + grp * 64 * CTD_ASTRIDE;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Hi = p.Hi, Wi = p.Wi, Ho = p.Ho, Wo = p.Wo, HWo = Ho * Wo;
+  const int ld = p.ld0;
+  const __bf16* const srcp = reinterpret_cast<const __bf16*>(p.src[0].ptr);
+
+  {
+    const __bf16* const wp = reinterpret_cast<const __bf16*>(p.w);   // [4 taps][Npad][Kpad = 64]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 512 * i;                   // 4 x 128 rows x 8 column groups = 4096
+      const int row = idx >> 3, c8 = idx & 7;
+      const int tap = row >> 7, n = row & 127;
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + ((size_t)tap * p.Npad + n) * p.Kpad + c8 * 8);
+      *reinterpret_cast<uint4*>(Wl + row * C64_STRIDE + c8 * 8) = v;
+    }
+    if (tid < 2) gcount[tid] = 0u;
+  }
+  __syncthreads();
+
+  // staging: load j of a thread is (row = (gtid >> 5) + 8 j, tap = (gtid >> 3) & 3, 8 channels c8 = gtid & 7); rows 0..31
+  // (j < 4) belong to the tile's first 32-pixel block, the others to the second
+  const int s_c8 = gtid & 7, s_tap = (gtid >> 3) & 3, s_r0 = gtid >> 5;
+  int roff[HL], aoff[HL];
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int row = s_r0 + 8 * j;
+    roff[j] = (((s_tap >> 1) * Wi) + 2 * (row & 31) + (s_tap & 1)) * 64 + s_c8 * 8;   // from the block's first source pixel
+    aoff[j] = row * CTD_ASTRIDE + s_tap * 64 + s_c8 * 8;
+  }
+  const int n_out = wn * 64 + li;                      // + 32 nb
+  const bool odd = li & 1;
+  int eoff[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int r = D16 ? 2 * e + (odd ? 1 : 0) : e;
+    eoff[e] = ((r & 3) + 8 * (r >> 2) + 4 * lh) * ld;
+  }
+
+  uint4 rh0, rh1, rh2, rh3, rh4, rh5, rh6, rh7;       // (scalars: as an array the compiler kept them in scratch memory)
+  auto issue_rows = [&](int t) {
+    auto block_base = [&](int p0) -> const __bf16* {    // first source pixel of a 32-pixel block (wave-uniform)
+      const int img = p0 / HWo;
+      const int rem = p0 - img * HWo;
+      const int y = rem / Wo, x0 = rem - y * Wo;
+      return srcp + (((long long)img * Hi + 2 * y) * Wi + 2 * x0) * 64;
+    };
+    const __bf16* const bb0 = block_base(t * 64);
+    const __bf16* const bb1 = block_base(t * 64 + 32);
+    rh0 = *reinterpret_cast<const uint4*>(bb0 + roff[0]); rh1 = *reinterpret_cast<const uint4*>(bb0 + roff[1]);
+    rh2 = *reinterpret_cast<const uint4*>(bb0 + roff[2]); rh3 = *reinterpret_cast<const uint4*>(bb0 + roff[3]);
+    rh4 = *reinterpret_cast<const uint4*>(bb1 + roff[4]); rh5 = *reinterpret_cast<const uint4*>(bb1 + roff[5]);
+    rh6 = *reinterpret_cast<const uint4*>(bb1 + roff[6]); rh7 = *reinterpret_cast<const uint4*>(bb1 + roff[7]);
+  };
+  auto commit_rows = [&]() {
+    *reinterpret_cast<uint4*>(Al + aoff[0]) = rh0; *reinterpret_cast<uint4*>(Al + aoff[1]) = rh1;
+    *reinterpret_cast<uint4*>(Al + aoff[2]) = rh2; *reinterpret_cast<uint4*>(Al + aoff[3]) = rh3;
+    *reinterpret_cast<uint4*>(Al + aoff[4]) = rh4; *reinterpret_cast<uint4*>(Al + aoff[5]) = rh5;
+    *reinterpret_cast<uint4*>(Al + aoff[6]) = rh6; *reinterpret_cast<uint4*>(Al + aoff[7]) = rh7;
+  };
+  auto store_tile = [&](f32x16 (&acc)[2], int t) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = n_out + 32 * nb;                    // < Ngemm = 128 (launch rule)
+      const long long base = (long long)(t * 64 + wm * 32) * ld + n;
+      if (D16) {
+        __bf16* const d = reinterpret_cast<__bf16*>(p.dst0) + base - (odd ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float mine_e = acc[nb][2 * e], mine_o = acc[nb][2 * e + 1];
+          const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+          *reinterpret_cast<unsigned*>(d + eoff[e]) = pack_bf16x2(odd ? got : keep, odd ? keep : got);
+        }
+      } else {
+        float* const d = reinterpret_cast<float*>(p.dst0) + base;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) d[eoff[e]] = acc[nb][e];
+      }
+    }
+  };
+
+  const int stride = 2 * (int)gridDim.x;
+  int t = 2 * (int)xcd_logical_id(blockIdx.x, gridDim.x) + grp;
+  unsigned gb_target = 0u;
+  unsigned* const gcnt = &gcount[grp];
+  if (t < ntiles) {
+    issue_rows(t);
+    commit_rows();
+    if (t + stride < ntiles) issue_rows(t + stride);
+    c64_group_barrier(gcnt, gb_target);
+  }
+  const int a_off = (wm * 32 + li) * CTD_ASTRIDE + lh * 8;
+  const int b_off = (wn * 64 + li) * C64_STRIDE + lh * 8;
+  for (; t < ntiles; t += stride) {
+    const int next = t + stride;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Al + a_off + tap * 64 + kk * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Wl + b_off + (tap * 128 + nb * 32) * C64_STRIDE + kk * 16);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[nb], 0, 0, 0);
+        }
+      }
+    c64_group_barrier(gcnt, gb_target);
+    if (next < ntiles) {
+      commit_rows();
+      if (next + stride < ntiles) issue_rows(next + stride);
+    }
+    store_tile(acc, t);
+    c64_group_barrier(gcnt, gb_target);
+  }
+}
+
 // ---- bf16 variant of the gather kernel (stride-2 convolutions, ConvTranspose as a 1x1 GEMM, their data gradients) ----
 // igemm_fast_kernel with bf16 matrix-core inputs: same per-row offsets / tap masks / live-tap list and epilogue; the staged
 // source pixels are rounded to bf16 after the norm-on-load transform, the weights arrive as bf16, LDS rows are 32 bf16 +
@@ -2778,6 +2920,17 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   } while (0)
     if (tr == 0) MSEG_CTP(0); else if (tr == 1) MSEG_CTP(1); else MSEG_CTP(2);
 #undef MSEG_CTP
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
+  if (p.precision == MSEG_PREC_BF16 && s16 && g_c64p_on && plain && p.epi == MSEG_EPI_PLAIN && p.KH == 2 && p.KW == 2 &&
+      p.stride == 2 && p.pad == 0 && p.mode == MSEG_MODE_CONV && p.morder == MSEG_MORDER_LINEAR && p.nsrc == 1 &&
+      p.Cin == 64 && p.Kpad == 64 && p.Ngemm == 128 && p.split >= p.Ngemm && !p.acc0 && !p.bias && (p.Wo % 32) == 0 &&
+      p.Hi == 2 * p.Ho && p.Wi == 2 * p.Wo && (M % 64) == 0 && M / 64 >= 4 * (long long)c64p_workgroups()) {
+    // data gradient of the level-0 ConvTranspose2d(128 -> 64): persistent workgroups with resident weights
+    const dim3 pgrid((unsigned)c64p_workgroups());
+    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctd_bf16_kernel<true>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
+    else hipLaunchKernelGGL((igemm_ctd_bf16_kernel<false>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
     MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }

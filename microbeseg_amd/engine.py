@@ -540,6 +540,13 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             # ConvTranspose2d(128 -> 64) of level 0 on bf16 tensors: the persistent kernel (mirror of the launcher's rule)
             tr = name.split(",")[2].strip()
             name = "igemm_ctp_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
+        elif epi == EPI_PLAIN and KH == 2 and KW == 2 and stride == 2 and pad == 0 and mode == MODE_CONV and \
+                morder == MORDER_LINEAR and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 64 and w.Kpad == 64 and \
+                Ngemm == 128 and p.split >= Ngemm and not acc0 and bias is None and srcs[0].act == ACT["none"] and \
+                not srcs[0].scale and Wo % 32 == 0 and (NB * Ho * Wo) % 64 == 0 and \
+                NB * Ho * Wo // 64 >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+            # data gradient of the level-0 ConvTranspose2d(128 -> 64) on bf16 tensors: the persistent kernel
+            name = "igemm_ctd_bf16_kernel<%s>" % ("true" if _st(dst0) == ST_BF16 else "false")
         elif name.startswith("igemm_halo_bf16w4_kernel<") and srcs[0].dtype == ST_BF16 and need == 0 and Wi % 8 == 0:
             # 128-channel tiles on bf16 tensors with enough pixels: 256-pixel tiles (mirror of the launcher's rule)
             tw = 32 if Wi % 32 == 0 else (16 if Wi % 16 == 0 else 8)

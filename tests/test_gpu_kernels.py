@@ -1016,3 +1016,33 @@ def test_bf16_storage_persistent_conv_transpose(eng, N, H, W, act, per_sample, d
             lib.mseg_igemm_set_persistent(1)
     assert rel_err(nchw(outs[0]), ref) < (6e-3 if act != "mish" else 8e-3)
     assert rel_err(outs[0], outs[1]) < 8e-3
+
+
+@pytest.mark.parametrize("N,h,w,dst32", [(16, 64, 64, False), (11, 64, 96, False), (17, 64, 64, True)])
+def test_bf16_storage_persistent_conv_transpose_dgrad(eng, N, h, w, dst32):
+    """Data gradient of ConvTranspose2d(128 -> 64, 2, stride 2) = Conv2d(64 -> 128, 2, stride 2) over dz, on bf16 tensors
+    with enough pixels: the persistent kernel (resident weights, 64-pixel tiles staged with all four taps) against torch on
+    the rounded operands and against the gather kernel (mseg_igemm_set_persistent(0)); bf16 and fp32 destinations, image
+    rows of 2 and 3 blocks, an odd tile count."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    Cin, Cout = 128, 64                                  # of the ConvTranspose2d; dz has Cout channels at (2h, 2w)
+    assert N * h * w // 64 >= 4 * torch.cuda.get_device_properties(0).multi_processor_count and w % 32 == 0
+    g = torch.Generator().manual_seed(3700 + N + w)
+    wt = rnd(g, Cin, Cout, 2, 2) / (Cout ** 0.5)
+    dz16 = _b16(rnd(g, N, Cout, 2 * h, 2 * w))
+    ref = F.conv2d(dz16.float(), _bf(wt), None, stride=2)        # weight (Cin, Cout, 2, 2) read as (out = Cin, in = Cout, 2, 2)
+    wp = eng.pack_weight(wt.cuda(), 4, Cin, Cout, 1, Cout * 4, 4)
+    dz = nhwc(dz16).cuda()
+    outs = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_persistent(on) == 0
+        try:
+            out = torch.full((N, h, w, Cin), float("nan"), device="cuda", dtype=torch.float32 if dst32 else torch.bfloat16)
+            eng.igemm([eng.plain_src(dz, Cout)], wp, None, N, 2 * h, 2 * w, h, w, 2, 2, 2, 0, eng.MODE_CONV, Cin, out, Cin,
+                      precision="bf16")
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_persistent(1)
+    assert rel_err(nchw(outs[0]), ref) < 6e-3
+    assert rel_err(outs[0], outs[1]) < 8e-3
