@@ -2262,13 +2262,176 @@ __global__ __launch_bounds__(512, 1) void igemm_ctp_bf16_kernel(const MsegIgemm 
   }
 }
 
+#define CTD_ASTRIDE 264         // bf16 per LDS row of 256 k + 8 pad (528 B: conflict-free 16-byte reads of consecutive rows)
+
+// ---- ... for the level-1 ConvTranspose2d(256 -> 128): 262 KB of weights, resident per OUTPUT POSITION ------------------------
+// A workgroup keeps the 256 x 128 weights of ONE of the four output positions (a, b) (68 KB) and computes that position for
+// its tiles; the four workgroups of a tile stream have neighbouring logical ids (one XCD): they walk the same tiles at the
+// same time, so the tile (64 pixels x 256 channels = 32 KB contiguous) comes from HBM once and from L2 three times.  A wave
+// owns 32 pixels x 64 of the 128 channels.
+template <int TR, bool D16>
+__global__ __launch_bounds__(512, 1) void igemm_ctp2_bf16_kernel(const MsegIgemm p, int ntiles) {
+  constexpr int HL = 8;                               // staging passes of a group: 64 rows x 32 threads over 256 threads
+  constexpr int NE = D16 ? 8 : 16;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[128 * CTD_ASTRIDE + 2 * 64 * CTD_ASTRIDE];
+  __shared__ unsigned gcount[2];
+  __bf16* const Wl = lds;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2;
+  const int gtid = tid & 255;
+  __bf16* const Al = lds + 128 * CTD_ASTRIDE + grp * 64 * CTD_ASTRIDE;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = gtid >> 5, scol = gtid & 31;       // staging: 8 rows x 32 groups of 8 channels per pass
+  const int H = p.Hi, W = p.Wi, HW = H * W;
+  const int Cq = p.Cq;                                // 128 output channels
+  const MsegSrc& s = p.src[0];
+  const __bf16* const srcp = reinterpret_cast<const __bf16*>(s.ptr);
+  const int lid = (int)xcd_logical_id(blockIdx.x, gridDim.x);
+  const int ab = lid & 3;                             // this workgroup's output position
+  const int stream = lid >> 2, nstreams = (int)gridDim.x >> 2;
+
+  {
+    const __bf16* const wp = reinterpret_cast<const __bf16*>(p.w) + (size_t)ab * Cq * p.Kpad;   // rows ab * 128 ..
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 512 * i;                   // 128 rows x 32 column groups = 4096
+      const int row = idx >> 5, c8 = idx & 31;
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + (size_t)row * p.Kpad + c8 * 8);
+      *reinterpret_cast<uint4*>(Wl + row * CTD_ASTRIDE + c8 * 8) = v;
+    }
+    if (tid < 2) gcount[tid] = 0u;
+  }
+  __syncthreads();
+
+  const bool odd = li & 1;
+  float bias[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) bias[h] = p.bias ? p.bias[wn * 64 + 32 * h + li] : 0.f;
+  // rows of this lane inside a 32-pixel block.  A block may wrap into the next image row once (W >= 32; W = 80 at 320 x 320
+  // crops): the wrapped rows sit 2 W Cq elements further (one output row of the other parity in between)
+  int eoff[NE], erow[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int r = D16 ? 2 * e + (odd ? 1 : 0) : e;
+    erow[e] = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    eoff[e] = erow[e] * 2 * Cq;
+  }
+  const int wrap = 2 * W * Cq;
+
+  uint4 rh0, rh1, rh2, rh3, rh4, rh5, rh6, rh7;
+  float4 tsc[2], tsh[2];
+  int ract = 0;
+  auto issue_rows = [&](int t) {
+    const __bf16* const tb = srcp + ((size_t)t * 64 + srow) * 256 + scol * 8;          // tile t: pixels 64 t .. 64 t + 63
+    rh0 = *reinterpret_cast<const uint4*>(tb); rh1 = *reinterpret_cast<const uint4*>(tb + 8 * 256);
+    rh2 = *reinterpret_cast<const uint4*>(tb + 16 * 256); rh3 = *reinterpret_cast<const uint4*>(tb + 24 * 256);
+    rh4 = *reinterpret_cast<const uint4*>(tb + 32 * 256); rh5 = *reinterpret_cast<const uint4*>(tb + 40 * 256);
+    rh6 = *reinterpret_cast<const uint4*>(tb + 48 * 256); rh7 = *reinterpret_cast<const uint4*>(tb + 56 * 256);
+    if (TR != 0) {
+      ract = s.act;
+      const bool has_aff = s.scale != nullptr;
+      const float* scp = has_aff ? s.scale : g_ident_scale;
+      const float* shp = has_aff ? s.shift : g_ident_shift;
+      const int img = (int)(((long long)t * 64) / HW);                         // a tile never spans two images (HW % 64 == 0)
+      const size_t o = (size_t)img * (has_aff ? (unsigned)s.ss : 0u) + scol * 8;
+      tsc[0] = *reinterpret_cast<const float4*>(scp + o); tsc[1] = *reinterpret_cast<const float4*>(scp + o + 4);
+      tsh[0] = *reinterpret_cast<const float4*>(shp + o); tsh[1] = *reinterpret_cast<const float4*>(shp + o + 4);
+    }
+  };
+  auto xf8 = [&](uint4 v) -> uint4 {
+    if (TR == 0) return v;
+    const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
+    float4 a = bf16x4_to_f32(make_uint2(v.x, v.y)), b = bf16x4_to_f32(make_uint2(v.z, v.w));
+    if (TR == 2) { a = act_fwd4(a, ract); b = act_fwd4(b, ract); }
+    else {
+      a.x = clamp_lo(a.x, lo); a.y = clamp_lo(a.y, lo); a.z = clamp_lo(a.z, lo); a.w = clamp_lo(a.w, lo);
+      b.x = clamp_lo(b.x, lo); b.y = clamp_lo(b.y, lo); b.z = clamp_lo(b.z, lo); b.w = clamp_lo(b.w, lo);
+    }
+    a.x = a.x * tsc[0].x + tsh[0].x; a.y = a.y * tsc[0].y + tsh[0].y; a.z = a.z * tsc[0].z + tsh[0].z; a.w = a.w * tsc[0].w + tsh[0].w;
+    b.x = b.x * tsc[1].x + tsh[1].x; b.y = b.y * tsc[1].y + tsh[1].y; b.z = b.z * tsc[1].z + tsh[1].z; b.w = b.w * tsc[1].w + tsh[1].w;
+    const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+    return make_uint4(pa.x, pa.y, pb.x, pb.y);
+  };
+  auto commit_rows = [&]() {
+    __bf16* const ab_ = Al + srow * CTD_ASTRIDE + scol * 8;
+    *reinterpret_cast<uint4*>(ab_) = xf8(rh0); *reinterpret_cast<uint4*>(ab_ + 8 * CTD_ASTRIDE) = xf8(rh1);
+    *reinterpret_cast<uint4*>(ab_ + 16 * CTD_ASTRIDE) = xf8(rh2); *reinterpret_cast<uint4*>(ab_ + 24 * CTD_ASTRIDE) = xf8(rh3);
+    *reinterpret_cast<uint4*>(ab_ + 32 * CTD_ASTRIDE) = xf8(rh4); *reinterpret_cast<uint4*>(ab_ + 40 * CTD_ASTRIDE) = xf8(rh5);
+    *reinterpret_cast<uint4*>(ab_ + 48 * CTD_ASTRIDE) = xf8(rh6); *reinterpret_cast<uint4*>(ab_ + 56 * CTD_ASTRIDE) = xf8(rh7);
+  };
+  auto store_tile = [&](f32x16 (&acc)[2], int t) {
+    const int p0 = t * 64 + wm * 32;                    // first input pixel of this wave's 32-row block
+    const int img = p0 / HW;
+    const int rem = p0 - img * HW;
+    const int y = rem / W, x0 = rem - y * W;
+    const long long pos = ((((long long)img * 2 * H + 2 * y + (ab >> 1)) * 2 * W) + 2 * x0 + (ab & 1)) * Cq + wn * 64 + li;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const long long base = pos + 32 * nb;
+      const float bv = bias[nb];
+      if (D16) {
+        __bf16* const d = reinterpret_cast<__bf16*>(p.dst0) + base - (odd ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float mine_e = acc[nb][2 * e] + bv, mine_o = acc[nb][2 * e + 1] + bv;
+          const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+          *reinterpret_cast<unsigned*>(d + eoff[e] + (x0 + erow[e] >= W ? wrap : 0)) = pack_bf16x2(odd ? got : keep, odd ? keep : got);
+        }
+      } else {
+        float* const d = reinterpret_cast<float*>(p.dst0) + base;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) d[eoff[e] + (x0 + erow[e] >= W ? wrap : 0)] = acc[nb][e] + bv;
+      }
+    }
+  };
+
+  const int stride = 2 * nstreams;
+  int t = 2 * stream + grp;
+  unsigned gb_target = 0u;
+  unsigned* const gcnt = &gcount[grp];
+  if (t < ntiles) {
+    issue_rows(t);
+    commit_rows();
+    if (t + stride < ntiles) issue_rows(t + stride);
+    c64_group_barrier(gcnt, gb_target);
+  }
+  const int a_off = (wm * 32 + li) * CTD_ASTRIDE + lh * 8;
+  const int b_off = (wn * 64 + li) * CTD_ASTRIDE + lh * 8;
+  for (; t < ntiles; t += stride) {
+    const int next = t + stride;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(Al + a_off + kk * 16);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Wl + b_off + nb * 32 * CTD_ASTRIDE + kk * 16);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[nb], 0, 0, 0);
+      }
+    }
+    c64_group_barrier(gcnt, gb_target);
+    if (next < ntiles) {
+      commit_rows();
+      if (next + stride < ntiles) issue_rows(next + stride);
+    }
+    store_tile(acc, t);
+    c64_group_barrier(gcnt, gb_target);
+  }
+}
+
 // ---- ... and for its data gradient: Conv2d(64 -> 128, 2, stride 2) over dz ------------------------------------------------
 // dx[p][ci] = sum over the 2 x 2 output positions (a, b) and co of dz[2 p + (a, b)][co] * W[ci][co][a][b]: M = low-resolution
 // pixels, K = 4 taps x 64 channels, N = 128.  Resident weights (4 x 128 rows of 64 k), tiles of 64 low-resolution pixels =
 // two 32-pixel blocks inside an image row, each staged with all four taps ([64 rows][256 k], 528-byte pitch): the two source
 // pixels of a row pair are adjacent in memory (256 contiguous bytes per pixel and image row).  A wave owns 32 pixels x 64
 // columns.  Plain operand (dz), one destination, no accumulation — anything else stays on the gather kernel.
-#define CTD_ASTRIDE 264         // bf16 per LDS row of the tile: 256 k + 8 pad (528 B)
 
 template <bool D16>
 __global__ __launch_bounds__(512, 1) void igemm_ctd_bf16_kernel(const MsegIgemm p, int ntiles) {
@@ -2920,6 +3083,24 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   } while (0)
     if (tr == 0) MSEG_CTP(0); else if (tr == 1) MSEG_CTP(1); else MSEG_CTP(2);
 #undef MSEG_CTP
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
+  if (p.precision == MSEG_PREC_BF16 && s16 && g_c64p_on && p.epi == MSEG_EPI_SCATTER2X2 && p.KH == 1 && p.KW == 1 &&
+      p.stride == 1 && p.pad == 0 && p.mode == MSEG_MODE_CONV && p.nsrc == 1 && p.Cin == 256 && p.Kpad == 256 &&
+      p.Cq == 128 && p.Ngemm == 512 && !p.acc0 && p.Wi >= 32 && (((long long)p.Hi * p.Wi) % 64) == 0 &&
+      (c64p_workgroups() & 3) == 0 && M / 64 >= 4 * (long long)(c64p_workgroups() / 4)) {
+    // ConvTranspose2d(256 -> 128, 2, stride 2) on bf16 tensors (level 1): weights resident per output position
+    const int tr = plain ? 0 : (generic ? 2 : 1);
+    const dim3 pgrid((unsigned)c64p_workgroups());
+    const int nt = (int)(M / 64);
+#define MSEG_CTP2(TR_)                                                                                               \
+  do {                                                                                                               \
+    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctp2_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
+    else hipLaunchKernelGGL((igemm_ctp2_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                    \
+  } while (0)
+    if (tr == 0) MSEG_CTP2(0); else if (tr == 1) MSEG_CTP2(1); else MSEG_CTP2(2);
+#undef MSEG_CTP2
     MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }

@@ -540,6 +540,13 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             # ConvTranspose2d(128 -> 64) of level 0 on bf16 tensors: the persistent kernel (mirror of the launcher's rule)
             tr = name.split(",")[2].strip()
             name = "igemm_ctp_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
+        elif epi == EPI_SCATTER2X2 and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 256 and w.Kpad == 256 and \
+                Cq == 128 and Ngemm == 512 and not acc0 and Wi >= 32 and (Hi * Wi) % 64 == 0 and \
+                torch.cuda.get_device_properties(dst0.device).multi_processor_count % 4 == 0 and \
+                NB * Hi * Wi // 64 >= torch.cuda.get_device_properties(dst0.device).multi_processor_count:
+            # ConvTranspose2d(256 -> 128) of level 1 on bf16 tensors: weights resident per output position
+            tr = name.split(",")[2].strip()
+            name = "igemm_ctp2_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
         elif epi == EPI_PLAIN and KH == 2 and KW == 2 and stride == 2 and pad == 0 and mode == MODE_CONV and \
                 morder == MORDER_LINEAR and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 64 and w.Kpad == 64 and \
                 Ngemm == 128 and p.split >= Ngemm and not acc0 and bias is None and srcs[0].act == ACT["none"] and \

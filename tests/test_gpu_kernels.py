@@ -1046,3 +1046,38 @@ def test_bf16_storage_persistent_conv_transpose_dgrad(eng, N, h, w, dst32):
             lib.mseg_igemm_set_persistent(1)
     assert rel_err(nchw(outs[0]), ref) < 6e-3
     assert rel_err(outs[0], outs[1]) < 8e-3
+
+
+@pytest.mark.parametrize("N,H,W,act,per_sample,dst32", [(4, 64, 64, "relu", False, False), (3, 96, 96, "mish", True, False),
+                                                         (5, 64, 64, "none", False, True), (4, 80, 80, "relu", False, False),
+                                                         (9, 48, 40, "relu", True, False)])
+def test_bf16_storage_persistent_conv_transpose_level1(eng, N, H, W, act, per_sample, dst32):
+    """ConvTranspose2d(256 -> 128, 2, stride 2) on bf16 tensors: the persistent kernel that keeps the weights of ONE output
+    position per workgroup (four workgroups share a tile stream) against torch on the rounded operands and against the gather
+    kernel (mseg_igemm_set_persistent(0))."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    Cin, Cout = 256, 128
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert N * H * W // 64 >= 4 * (cus // 4) and W >= 32 and (H * W) % 64 == 0     # rows of 80 / 40 pixels: blocks wrap
+    g = torch.Generator().manual_seed(4100 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    nsc = (N, Cin) if per_sample else (Cin,)
+    scale, shift = rnd(g, *nsc) * 0.3 + 1.0, rnd(g, *nsc) * 0.1
+    wt, bt = rnd(g, Cin, Cout, 2, 2) / (Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv_transpose2d(_bf(_transform_cpu(z16.float(), act, scale, shift, per_sample)), _bf(wt), bt, stride=2)
+    node = _mk_node(eng, z16.float(), act, scale, shift, per_sample)
+    node.z = node.z.to(torch.bfloat16)
+    wpt = eng.pack_weight(wt.cuda(), 4, Cout, Cin, 1, 4, Cout * 4, merge_taps=True)
+    outs = []
+    for on in (1, 0):
+        assert lib.mseg_igemm_set_persistent(on) == 0
+        try:
+            out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.float32 if dst32 else torch.bfloat16)
+            eng.igemm([node.src()], wpt, bt.cuda(), N, H, W, H, W, 1, 1, 1, 0, eng.MODE_CONV, 4 * Cout, out, Cout,
+                      epi=eng.EPI_SCATTER2X2, Cq=Cout, precision="bf16")
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_persistent(1)
+    assert rel_err(nchw(outs[0]), ref) < (6e-3 if act != "mish" else 8e-3)
+    assert rel_err(outs[0], outs[1]) < 8e-3
