@@ -2573,7 +2573,7 @@ __global__ __launch_bounds__(512, 1) void igemm_ctd_bf16_kernel(const MsegIgemm 
 // pad (80 B), one K-step (one tap x 32 channels) is two v_mfma_f32_32x32x16_bf16 per 32 x 32 block.
 // S16: bf16 source tensors; a staging thread then owns 8 channels of a row (one 16-byte load), half as many passes.
 template <int BM, int BN, int TR, bool PER_SAMPLE, bool S16>
-__global__ __launch_bounds__(256, 4) void igemm_fast_bf16_kernel(const MsegIgemm p) {
+__global__ __launch_bounds__(256, PER_SAMPLE ? 2 : 4) void igemm_fast_bf16_kernel(const MsegIgemm p) {
   using Cfg = IgemmCfg<BM, BN>;
   constexpr int STAGE = (BM + BN) * HB_STRIDE;
   constexpr int BPASS = BN / 64;                       // weight staging: 64 rows x 4 groups of 8 channels per pass
