@@ -255,6 +255,23 @@ int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* 
 int mseg_ranger_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, int rows, double beta1,
                      double beta2, double eps, double step_lr, int rectified, int do_gc, int lookahead, double alpha,
                      void* stream);
+/* The same update for many parameter tensors (ranger2020.py:117-206, the loop over group['params']): `jobs` are njobs
+ * records in HOST memory; they travel in kernel arguments, 48 per launch.  rows > 0: gradient centralisation with rows =
+ * shape[0]; rows = 0: none.  step_lr / flags are per tensor because the reference keeps `step` per parameter.         */
+typedef struct MsegRangerJob {
+  float* p;
+  const float* g;
+  float* m;        /* exp_avg     */
+  float* v;        /* exp_avg_sq  */
+  float* slow;     /* slow_buffer */
+  uint64_t n;
+  int32_t rows;
+  float step_lr;   /* step_size * lr */
+  uint32_t flags;  /* bit 0: rectified (N_sma > threshold), bit 1: lookahead blend this step */
+  uint32_t reserved;
+} MsegRangerJob;
+int mseg_ranger_step_multi(const MsegRangerJob* jobs, int njobs, double beta1, double beta2, double eps, double alpha,
+                           void* stream);
 
 /* ---- inference post-processing (src/inference/postprocessing.py) --------------------------------------------
  * distance_postprocessing(border, cell, th_seed, th_cell) (postprocessing.py:7-59) and

@@ -54,6 +54,12 @@ class MsegPackJob(C.Structure):
                 ("first_block", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class MsegRangerJob(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("slow", C.c_void_p),
+                ("n", C.c_uint64), ("rows", C.c_int32), ("step_lr", C.c_float), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -93,6 +99,7 @@ SIGNATURES = {
     "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, C.c_double, _P, _P, _P]),
     "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _D, _D, _D, _I, _P]),
     "mseg_ranger_step": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _D, _D, _D, _D, _I, _I, _I, _D, _P]),
+    "mseg_ranger_step_multi": (_I, [_P, _I, _D, _D, _D, _D, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_postproc_tuning": (_I, [_I, _I, _I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),

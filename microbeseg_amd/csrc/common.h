@@ -89,6 +89,29 @@ __device__ __forceinline__ float act_bwd_fast(float z, int act) {
   return act_bwd(z, act);
 }
 
+// a = act(z) and act'(z) together (the backward norm pass needs both; Mish / ELU share their exponential).  `a` is
+// bit-identical to act_fwd / act_fwd_fast of the same z — the forward pass stored exactly that value.
+template <bool FAST>
+__device__ __forceinline__ void act_pair(float z, int act, float& a, float& d) {
+  if (act == MSEG_ACT_MISH) {
+    if (z > 20.f) { a = z; d = 1.f; return; }
+    const float w = FAST ? __expf(z) : expf(z);
+    const float n = w * (w + 2.f);
+    if (FAST) {
+      const float r = __frcp_rn(n + 2.f);
+      a = z * n * r;
+      d = n * r + 4.f * z * w * (w + 1.f) * r * r;
+    } else {
+      const float r = 1.f / (n + 2.f);
+      a = z * (n / (n + 2.f));
+      d = n * r + 4.f * z * w * (w + 1.f) * r * r;
+    }
+    return;
+  }
+  a = FAST ? act_fwd_fast(z, act) : act_fwd(z, act);
+  d = FAST ? act_bwd_fast(z, act) : act_bwd(z, act);
+}
+
 __device__ __forceinline__ float4 act_fwd4(float4 v, int act) {
   if (act == MSEG_ACT_NONE) return v;
   if (act == MSEG_ACT_RELU) {

@@ -314,3 +314,90 @@ extern "C" int mseg_ranger_step(float* p, const float* g, float* m, float* v, fl
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
+
+// ---- the same update for MANY parameter tensors in one launch --------------------------------------------------
+// A network has ~250 parameter tensors, most of them tiny (biases, norm weights): one launch each costs more than the
+// 28..36 B/param of traffic.  Up to RANGER_BATCH job records travel in the kernel arguments (no device table to keep
+// in step with autograd's fresh gradient tensors); a workgroup finds its job by its first block and then runs
+// ranger_step_kernel's row update.
+#define RANGER_BATCH 48
+struct RangerBatch {
+  MsegRangerJob job[RANGER_BATCH];
+  unsigned first[RANGER_BATCH + 1];
+  int njobs;
+};
+
+__global__ __launch_bounds__(256) void ranger_step_multi_kernel(const RangerBatch b, float beta1, float w1, float beta2,
+                                                                float w2, float eps, float alpha) {
+  __shared__ double sh[4];
+  int lo = 0, hi = b.njobs - 1;              // uniform: scalar loads from the kernel-argument segment
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const MsegRangerJob& J = b.job[lo];
+  const unsigned row = blockIdx.x - b.first[lo];
+  const bool do_gc = J.rows > 0;
+  const size_t n = J.n;
+  const size_t cols = do_gc ? n / (size_t)J.rows : 4096;
+  const size_t base = (size_t)row * cols;
+  size_t len = cols;
+  if (base + len > n) len = n - base;
+  float* __restrict__ p = J.p;
+  const float* __restrict__ g = J.g;
+  float* __restrict__ m = J.m;
+  float* __restrict__ v = J.v;
+  float* __restrict__ slow = J.slow;
+  const float step_lr = J.step_lr;
+  const bool rectified = J.flags & 1, lookahead = J.flags & 2;
+  float mean = 0.f;
+  if (do_gc) {
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < len; i += blockDim.x) s += (double)g[base + i];
+    s = block_sum(s, sh);
+    mean = (float)(s / (double)len);
+  }
+  for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
+    const size_t j = base + i;
+    const float gi = g[j] - mean;
+    const float vi = v[j] * beta2 + w2 * (gi * gi);
+    const float mi = m[j] * beta1 + w1 * gi;
+    v[j] = vi; m[j] = mi;
+    const float upd = rectified ? mi / (sqrtf(vi) + eps) : mi;
+    float pi = p[j] - step_lr * upd;
+    if (lookahead) {
+      const float sl = slow[j] + alpha * (pi - slow[j]);
+      slow[j] = sl;
+      pi = sl;
+    }
+    p[j] = pi;
+  }
+}
+
+extern "C" int mseg_ranger_step_multi(const MsegRangerJob* jobs, int njobs, double beta1, double beta2, double eps,
+                                      double alpha, void* stream) {
+  if (!jobs || njobs <= 0) return MSEG_EINVAL;
+  for (int i = 0; i < njobs; ++i) {
+    const MsegRangerJob& J = jobs[i];
+    if (!J.p || !J.g || !J.m || !J.v || !J.slow || J.n == 0 || J.rows < 0) return MSEG_EINVAL;
+    if (J.rows > 0 && J.n % (uint64_t)J.rows) return MSEG_EINVAL;
+    if ((J.rows > 0 ? (uint64_t)J.rows : (J.n + 4095) / 4096) > 0x7fffffffull) return MSEG_EINVAL;
+  }
+  for (int at = 0; at < njobs; at += RANGER_BATCH) {
+    RangerBatch b;
+    b.njobs = njobs - at < RANGER_BATCH ? njobs - at : RANGER_BATCH;
+    uint64_t blocks = 0;
+    for (int i = 0; i < b.njobs; ++i) {
+      b.job[i] = jobs[at + i];
+      b.first[i] = (unsigned)blocks;
+      blocks += b.job[i].rows > 0 ? (uint64_t)b.job[i].rows : (b.job[i].n + 4095) / 4096;
+      if (blocks > 0x7fffffffull) return MSEG_EINVAL;
+    }
+    for (int i = b.njobs; i < RANGER_BATCH; ++i) { b.job[i] = b.job[0]; b.first[i] = (unsigned)blocks; }
+    b.first[RANGER_BATCH] = (unsigned)blocks;
+    hipLaunchKernelGGL(ranger_step_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b,
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)alpha);
+    MSEG_LAUNCH_CHECK();
+  }
+  return MSEG_OK;
+}

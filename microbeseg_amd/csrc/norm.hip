@@ -61,6 +61,16 @@ struct NormVec {
       v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
     }
   }
+  // v as a store + load of the tensor would return it
+  static __device__ __forceinline__ void round(float (&v)[V]) {
+    if (S16) {
+#pragma unroll
+      for (int j = 0; j < V; j += 2) {
+        const uint32_t r = pack_bf16x2(v[j], v[j + 1]);
+        v[j] = bf16_lo(r); v[j + 1] = bf16_hi(r);
+      }
+    }
+  }
   // stores v (rounding to bf16 for S16) and returns the values AS STORED in v
   static __device__ __forceinline__ void put(void* base, size_t e, float (&v)[V]) {
     if (S16) {
@@ -78,12 +88,13 @@ struct NormVec {
 
 // MODE 0: forward  sums of (a, a*a)           from z        (+ optional store of a = act(z) into `aio`)
 // MODE 1: backward sums of (gy, gy*a)         from (gy, z)  (a read from `aio` when given)
-// MODE 2: backward apply: dz = (k1*gy + k2*a + k3) * act'(z), sums of (dz)
+// MODE 2: backward apply: dz = (k1*gy + k2*a + k3) * act'(z), sums of (dz)  (a recomputed from z, never read)
 // MODE 3: a = act(z) only (eval-mode BatchNorm with an expensive activation: materialise it once for the consumers)
 // `aio`: for expensive activations (Mish / ELU / LeakyReLU path) the activated tensor is materialised once so that the
 // conv / wgrad K-loops do not re-evaluate transcendentals for each of the 9 taps and every output tile.
 // S16: z, gy, dz and aio are bf16 tensors (the sums are taken over the values as stored, i.e. of the rounded dz).
-template <int MODE, bool S16>
+// AIO: the launch carries `aio` (compile-time, so that the ReLU / no-activation passes keep their exact code)
+template <int MODE, bool S16, bool AIO>
 __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__ z, const void* __restrict__ gy,
                                                         void* __restrict__ dz, const float* __restrict__ k1,
                                                         const float* __restrict__ k2, const float* __restrict__ k3,
@@ -129,8 +140,8 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
           const int ru = r + u * rpi;
           ok[u] = ru < row_end;
           const size_t off = ((size_t)n * g.HW + (ok[u] ? ru : r)) * g.C + c;
-          zv[u].load(z, off);
-          if ((MODE == 1 || MODE == 2) && aio) av[u].load(aio, off);
+          if (MODE != 1 || !AIO) zv[u].load(z, off);            // the sums of MODE 1 need a only: z stays in HBM when a is stored
+          if (MODE == 1 && AIO) av[u].load(aio, off);           // MODE 2 recomputes a next to act'(z) instead (act_pair)
           if (MODE == 1 || MODE == 2) gv[u].load(gy, off);
         }
 #pragma unroll
@@ -138,8 +149,21 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
           if (!ok[u]) continue;
           const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
           float zf[V], a4[V];
-          zv[u].get(zf);
-          if ((MODE == 1 || MODE == 2) && aio) av[u].get(a4);
+          if (MODE != 1 || !AIO) zv[u].get(zf);
+          if (MODE == 2 && AIO) {                 // expensive activation: a (as the forward stored it) and act'(z) in one go
+            float gf[V], d[V];
+            gv[u].get(gf);
+#pragma unroll
+            for (int j = 0; j < V; ++j) act_pair<S16>(zf[j], act, a4[j], d[j]);
+            NormVec<S16>::round(a4);
+#pragma unroll
+            for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * d[j];
+            NormVec<S16>::put(dz, off, d);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s0[j] += d[j];
+            continue;
+          }
+          if (MODE == 1 && AIO) av[u].get(a4);
           else {
             if (S16 && act != MSEG_ACT_NONE && act != MSEG_ACT_RELU) {
 #pragma unroll
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
               }
             }
           }
-          if ((MODE == 0 || MODE == 3) && aio)
+          if ((MODE == 0 || MODE == 3) && AIO)
             NormVec<S16>::put(aio, off, a4);      // the consumers read the ROUNDED activation: the statistics describe that
           if (MODE == 3) continue;
           if (MODE == 0) {
@@ -386,10 +410,17 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
   return (unsigned)(b > cap ? cap : b);
 }
 
-#define NORM_PASS(MODE_, ...)                                                                                        \
+#define NORM_PASS_A(MODE_, S16_, ...)                                                                                \
   do {                                                                                                               \
-    if (st_ == MSEG_ST_BF16) hipLaunchKernelGGL((norm_pass_kernel<MODE_, true>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((norm_pass_kernel<MODE_, false>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__);     \
+    if (aio_) hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, true>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__, aio_); \
+    else hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, false>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__, aio_);     \
+  } while (0)
+// the last kernel argument (`aio`: stored activation, nullable) also selects the instantiation
+#define NORM_PASS(MODE_, AIO_, ...)                                                                                  \
+  do {                                                                                                               \
+    auto aio_ = (AIO_);                                                                                              \
+    if (st_ == MSEG_ST_BF16) NORM_PASS_A(MODE_, true, __VA_ARGS__);                                                  \
+    else NORM_PASS_A(MODE_, false, __VA_ARGS__);                                                                     \
   } while (0)
 
 extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int act, int norm, const float* gamma,
@@ -406,8 +437,8 @@ extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int
   NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
   double* part = (double*)ws;
   double* nc = part + (size_t)N * g.chunks * 3 * C;
-  NORM_PASS(0, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
-            (const float*)nullptr, 0, g, act, part, act_out);
+  NORM_PASS(0, act_out, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
+            (const float*)nullptr, 0, g, act, part);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -424,8 +455,8 @@ extern "C" int mseg_activation(const void* z, int N, int HW, int C, int st_, int
   if ((st_ != MSEG_ST_F32 && st_ != MSEG_ST_BF16) || (st_ == MSEG_ST_BF16 && (C & 7))) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
-  NORM_PASS(3, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
-            (const float*)nullptr, 0, g, act, (double*)nullptr, act_out);
+  NORM_PASS(3, act_out, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
+            (const float*)nullptr, 0, g, act, (double*)nullptr);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -455,8 +486,8 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   float* k2 = k1 + (size_t)N * C;
   float* k3 = k2 + (size_t)N * C;
   const int kss = (norm == MSEG_NORM_BN) ? 0 : C;
-  NORM_PASS(1, z, gy, (void*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, g, act,
-            part, const_cast<void*>(act_in));
+  NORM_PASS(1, const_cast<void*>(act_in), z, gy, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
+            (const float*)nullptr, 0, g, act, part);
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
@@ -465,8 +496,8 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
                      st, (const double*)nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta);
   MSEG_LAUNCH_CHECK();
   double* part2 = part;
-  NORM_PASS(2, z, gy, dz, (const float*)k1, (const float*)k2, (const float*)k3, kss, g, act, part2,
-            const_cast<void*>(act_in));
+  NORM_PASS(2, const_cast<void*>(act_in), z, gy, dz, (const float*)k1, (const float*)k2, (const float*)k3, kss, g, act,
+            part2);
   MSEG_LAUNCH_CHECK();
   if (dbias) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,

@@ -69,10 +69,9 @@ class Ranger(Optimizer):
             slot[0], slot[1], slot[2] = step, n_sma, size
         return slot[1], slot[2]
 
-    def _fused_step(self, p, state, group, beta1, beta2):
-        """MI355X path: the whole per-tensor update is ONE HIP kernel (csrc/loss.hip: ranger_step_kernel)."""
-        from .. import _lib
-        lib = _lib.load()
+    def _fused_job(self, job, p, state, group, beta1, beta2):
+        """MI355X path: fill the record of `p` for the multi-tensor launch (csrc/loss.hip: ranger_step_multi_kernel does
+        the whole update of every tensor of the group: centralisation, moments, rectified step, lookahead)."""
         if len(state) == 0:
             state['step'] = 0
             state['exp_avg'] = torch.zeros_like(p)
@@ -81,21 +80,33 @@ class Ranger(Optimizer):
         state['step'] += 1
         n_sma, step_size = self._rectification(state['step'], beta1, beta2)
         g = p.grad.detach().contiguous()
-        do_gc = int(self.use_gc and g.dim() > (3 if self.gc_conv_only else 1))
-        rows = g.shape[0] if do_gc else 1
-        lookahead = int(state['step'] % group['k'] == 0)
-        _lib.check(lib.mseg_ranger_step(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(),
-                                        state['exp_avg_sq'].data_ptr(), state['slow_buffer'].data_ptr(), p.numel(),
-                                        rows, beta1, beta2, group['eps'], step_size * group['lr'],
-                                        int(n_sma > self.N_sma_threshhold), do_gc, lookahead, self.alpha,
-                                        torch.cuda.current_stream().cuda_stream), "ranger_step")
-        torch.autograd.graph.increment_version(p)    # written through a raw pointer: packed operands are now stale
+        do_gc = self.use_gc and g.dim() > (3 if self.gc_conv_only else 1)
+        job.p, job.g = p.data_ptr(), g.data_ptr()
+        job.m, job.v, job.slow = (state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                                  state['slow_buffer'].data_ptr())
+        job.n = p.numel()
+        job.rows = g.shape[0] if do_gc else 0
+        job.step_lr = step_size * group['lr']
+        job.flags = int(n_sma > self.N_sma_threshhold) | (int(state['step'] % group['k'] == 0) << 1)
+        return g                                     # kept alive until the launch is enqueued
+
+    def _fused_group(self, ps, group, beta1, beta2):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        jobs = (_lib.MsegRangerJob * len(ps))()
+        keep = [self._fused_job(j, p, self.state[p], group, beta1, beta2) for j, p in zip(jobs, ps)]
+        _lib.check(lib.mseg_ranger_step_multi(ctypes.addressof(jobs), len(ps), beta1, beta2, group['eps'], self.alpha,
+                                              torch.cuda.current_stream(ps[0].device).cuda_stream), "ranger_step_multi")
+        del keep
+        torch.autograd.graph.increment_version(ps)   # written through raw pointers: packed operands are now stale
 
     @torch.no_grad()
     def step(self, closure=None):
         fused = []
         for group in self.param_groups:
             beta1, beta2 = group['betas']
+            batch = {}
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -103,8 +114,7 @@ class Ranger(Optimizer):
                     raise RuntimeError('Ranger optimizer does not support sparse gradients')
                 state = self.state[p]
                 if p.is_cuda and p.dtype == torch.float32 and group['weight_decay'] == 0 and self.gc_loc:
-                    self._fused_step(p, state, group, beta1, beta2)
-                    fused.append(p)
+                    batch.setdefault(p.device, []).append(p)
                     continue
                 grad = p.grad.detach().float().clone()
                 if len(state) == 0:
@@ -132,6 +142,9 @@ class Ranger(Optimizer):
                     slow = state['slow_buffer']
                     slow.add_(p - slow, alpha=self.alpha)
                     p.copy_(slow)
+            for ps in batch.values():                # the CUDA parameters of the group: one launch per 48 tensors
+                self._fused_group(ps, group, beta1, beta2)
+                fused += ps
         if fused:            # all packed convolution operands of the updated weights in ONE launch (engine.repack_all)
             from .. import engine
             engine.repack_all(fused)

@@ -204,6 +204,61 @@ def test_fused_adam_equals_torch_adam(dev):
             assert rel_err(sb[key].cpu(), sa[key].cpu()) < 2e-6, key
 
 
+def test_ranger_multi_tensor_step(dev):
+    """Ranger.step() updates all CUDA tensors of a group with mseg_ranger_step_multi (48 tensors per launch): bit-identical
+    to mseg_ranger_step called per tensor, and the optimizer follows its own torch path (CPU parameters) over 14 steps
+    (past the rectification threshold and two lookahead blends), with one parameter skipping a step."""
+    import ctypes as C
+    from microbeseg_amd import _lib
+    from microbeseg_amd.training.ranger2020 import Ranger
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(33)
+    shapes = [(16, 8, 3, 3), (16,), (5, 3, 2, 2), (9000,), (1, 4, 1, 1), (3,)] * 10 + [(256, 300)]     # 61 tensors
+    # (a) the kernel against the per-tensor entry point
+    mk = lambda: [torch.randn(s, generator=g).to(dev) for s in shapes]
+    p0, gr, m0, v0, s0 = mk(), mk(), mk(), [t.abs() for t in mk()], mk()
+    one = [[t.clone() for t in ts] for ts in (p0, m0, v0, s0)]
+    many = [[t.clone() for t in ts] for ts in (p0, m0, v0, s0)]
+    jobs = (_lib.MsegRangerJob * len(shapes))()
+    stream = torch.cuda.current_stream().cuda_stream
+    for i, shp in enumerate(shapes):
+        rows = shp[0] if len(shp) > 1 else 0
+        rect, look, lr = i % 2, (i // 2) % 2, 1e-3 * (1 + i % 3)
+        _lib.check(lib.mseg_ranger_step(one[0][i].data_ptr(), gr[i].data_ptr(), one[1][i].data_ptr(),
+                                        one[2][i].data_ptr(), one[3][i].data_ptr(), gr[i].numel(), max(rows, 1), 0.95,
+                                        0.999, 1e-5, lr, rect, int(rows > 0), look, 0.5, stream), "ranger_step")
+        j = jobs[i]
+        j.p, j.g, j.m, j.v, j.slow = (many[0][i].data_ptr(), gr[i].data_ptr(), many[1][i].data_ptr(),
+                                      many[2][i].data_ptr(), many[3][i].data_ptr())
+        j.n, j.rows, j.step_lr, j.flags = gr[i].numel(), rows, lr, rect | (look << 1)
+    _lib.check(lib.mseg_ranger_step_multi(C.addressof(jobs), len(shapes), 0.95, 0.999, 1e-5, 0.5, stream), "multi")
+    for a, b in zip(one, many):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert lib.mseg_ranger_step_multi(C.addressof(jobs), 0, 0.95, 0.999, 1e-5, 0.5, stream) != 0
+    # (b) the optimizer on the device against its torch path on the CPU
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    pc = [torch.nn.Parameter(t.clone()) for t in init]
+    pd = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    with contextlib.redirect_stdout(io.StringIO()):
+        oc, od = (Ranger(ps, lr=6e-3, eps=1e-6) for ps in (pc, pd))
+    for step in range(14):
+        for i, (a, b, shp) in enumerate(zip(pc, pd, shapes)):
+            if step == 3 and i == 1:
+                a.grad = b.grad = None                 # this tensor's step counter falls behind the others
+                continue
+            t = torch.randn(shp, generator=g) * (10.0 ** (step % 3 - 2))
+            a.grad, b.grad = t.clone(), t.clone().to(dev)
+        oc.step()
+        od.step()
+    for a, b in zip(pc, pd):
+        assert rel_err(b.detach().cpu(), a.detach()) < 5e-6
+        assert oc.state[a]["step"] == od.state[b]["step"]
+        for key in ("exp_avg", "exp_avg_sq", "slow_buffer"):
+            assert rel_err(od.state[b][key].cpu(), oc.state[a][key]) < 5e-6, key
+    assert od.state[pd[1]]["step"] == 13
+
+
 def _l2_rel(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
