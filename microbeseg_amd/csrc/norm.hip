@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
       }
       // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
       // one load pair per trip left the pass latency-bound at ~3 TB/s
-      constexpr int U = (S16 && (MODE == 1 || MODE == 2)) ? 2 : 4;   // measured: the 2-3 operand bf16 passes need the registers
+      constexpr int U = (MODE == 0 && !AIO) ? 8 : !S16 ? 4 : MODE == 1 ? (AIO ? 2 : 4) : MODE == 2 ? 2 : 4;   // measured per pass (registers vs loads in flight)
       for (int r = row_begin + r0; r < row_end; r += rpi * U) {
         NormVec<S16> zv[U], gv[U], av[U];
         bool ok[U];
