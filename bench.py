@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--filters", type=int, nargs=2, default=[64, 1024])
     ap.add_argument("--optimizer", default="adam", choices=["adam", "ranger"])
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE configs[2]: bf16 matrix-core inputs for the 3x3 stride-1 convolutions, fp32 "
-                         "accumulate / storage / normalisation statistics (the default line is the fp32 configs[1])")
+                    help="bf16 = BASELINE configs[2]: bf16 matrix-core kernels for every convolution that has one, "
+                         "activations and activation gradients STORED as bf16 (DESIGN.md 4b), fp32 accumulate / weights / "
+                         "normalisation statistics (the default line is the fp32 configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracketing of MFMA kernels")
     ap.add_argument("--graph", action="store_true",

@@ -97,6 +97,21 @@ typedef struct MsegIgemm {
 } MsegIgemm;
 
 int mseg_igemm(const MsegIgemm* p, void* stream);
+
+/* Which kernel a call maps to.  The query runs the SAME dispatch code as the call it describes and launches nothing
+ * (no device work, no stream): same argument checks, same return code (MSEG_EINVAL: no kernel for this descriptor, e.g.
+ * MSEG_PREC_BF16 on a shape that has no bf16 kernel), so host code never has to restate a dispatch rule.
+ * `name` is the instantiation as rocprofv3's kernel trace prints it, without "void " and the argument list. */
+typedef struct MsegKernelInfo {
+  char name[120];
+  int32_t precision; /* MSEG_PREC_* the kernel computes in */
+  int32_t launches;  /* kernel launches of the call (split-K partial + reduction = 2; one-off table initialisation counted) */
+  uint32_t grid, block;
+  size_t workspace;  /* split-K scratch bytes the call uses (0: none) */
+} MsegKernelInfo;
+int mseg_igemm_query(const MsegIgemm* p, MsegKernelInfo* info);
+/* name of the main kernel of this thread's last mseg_igemm / mseg_wgrad call ("" before the first) */
+const char* mseg_last_kernel(void);
 /* round-to-nearest-even conversion of n floats to bf16 (the packed weights of a MSEG_PREC_BF16 launch) */
 int mseg_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* bytes of split-K scratch this launch would use (0: it would not be split) */
@@ -108,6 +123,10 @@ int mseg_igemm_set_persistent(int on);
 /* Test / ablation hook: on = 0 sends the 128-channel-tile bf16 layers back from 256-pixel to 128-pixel tiles
  * (igemm_halo_bf16w4m_kernel -> igemm_halo_bf16w4_kernel).  Same results up to the fp32 accumulation order.  Default 1. */
 int mseg_igemm_set_wide_tiles(int on);
+/* Test / ablation hook for the one-workgroup-per-CU kernel with DMA-streamed weights (igemm_p8.hip: 3x3 stride-1 layers
+ * with >= 128 output channels on bf16 tensors): 0 = off (the tile-per-workgroup kernels above), 1 = on (default),
+ * 2 = on, 128-channel layers on 256-pixel instead of 512-pixel tiles.  Same results up to the fp32 accumulation order. */
+int mseg_igemm_set_p8(int mode);
 
 /* weight gradient: G[t][mch][nch] = sum_p P[p][mch] * Q[gather(p, t)][nch], written to dst[(mch*Nch + nch)*T + t]
  * which *is* torch's layout for both Conv2d.weight (Cout,Cin,KH,KW) [P = dz, Q = conv input] and
@@ -131,6 +150,7 @@ typedef struct MsegWgrad {
 
 size_t mseg_wgrad_workspace_bytes(const MsegWgrad* p);
 int mseg_wgrad(const MsegWgrad* p, void* stream);
+int mseg_wgrad_query(const MsegWgrad* p, MsegKernelInfo* info);
 
 /* The network's first convolution, Conv2d(ch_in <= 4, Cout, 3, padding=1) (unets.py:303-304,413-414), and its weight
  * gradient for ch_in == 1: HBM-bound VALU kernels (9..36 multiply-adds per output), not worth a 32-channel matrix-core

@@ -47,6 +47,11 @@ class MsegWgrad(C.Structure):
                 ("splits", C.c_int32), ("phase", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MsegKernelInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 120), ("precision", C.c_int32), ("launches", C.c_int32), ("grid", C.c_uint32),
+                ("block", C.c_uint32), ("workspace", C.c_size_t)]
+
+
 class MsegPackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst16", C.c_void_p),
                 ("T", C.c_int32), ("R", C.c_int32), ("Rpad", C.c_int32), ("C", C.c_int32), ("Cpad", C.c_int32),
@@ -70,14 +75,18 @@ _SZ = C.c_size_t
 SIGNATURES = {
     "mseg_igemm": (_I, [C.POINTER(MsegIgemm), _P]),
     "mseg_igemm_workspace_bytes": (_SZ, [C.POINTER(MsegIgemm)]),
+    "mseg_igemm_query": (_I, [C.POINTER(MsegIgemm), C.POINTER(MsegKernelInfo)]),
+    "mseg_last_kernel": (C.c_char_p, []),
     "mseg_igemm_set_persistent": (_I, [_I]),
     "mseg_igemm_set_wide_tiles": (_I, [_I]),
+    "mseg_igemm_set_p8": (_I, [_I]),
     "mseg_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
     "mseg_wgrad": (_I, [C.POINTER(MsegWgrad), _P]),
+    "mseg_wgrad_query": (_I, [C.POINTER(MsegWgrad), C.POINTER(MsegKernelInfo)]),
     "mseg_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mseg_pack_job_blocks": (C.c_uint, [_I, _I, _I]),
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libmseg_hip.so
-SRCS="igemm.hip wgrad.hip first.hip norm.hip head.hip loss.hip augment.hip labels.hip polygons.hip api_misc.hip"
+SRCS="igemm.hip igemm_p8.hip wgrad.hip first.hip norm.hip head.hip loss.hip augment.hip labels.hip polygons.hip api_misc.hip"
 [ -f postproc.hip ] && SRCS="$SRCS postproc.hip"
 mkdir -p ../_build
 OBJS=""
@@ -11,7 +11,7 @@ pids=()
 for s in $SRCS; do
   o=../_build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ igemm_common.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
     # -pragma-unroll-threshold: the fully unrolled epilogues exceed LLVM's default 16k-instruction cap for "#pragma unroll";
     # a loop left rolled would index the accumulator array dynamically and push it to scratch memory
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=200000 -c "$s" -o "$o" &

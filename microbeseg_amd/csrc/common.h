@@ -5,14 +5,35 @@
 #include "../../include/mseg_hip.h"
 
 extern "C" void mseg_set_hip_error(int e);
+extern "C" int mseg_dispatch_dry(void);
 
 #define MSEG_LAUNCH_CHECK()                           \
   do {                                                \
+    if (mseg_dispatch_dry()) break;                   \
     hipError_t e__ = hipGetLastError();               \
     if (e__ != hipSuccess) {                          \
       mseg_set_hip_error((int)e__);                   \
       return MSEG_ELAUNCH;                            \
     }                                                 \
+  } while (0)
+
+// Every kernel launch of the dispatchers goes through these: the call records which kernel a launch maps to
+// (mseg_last_kernel, MsegKernelInfo) and — in a query (mseg_igemm_query / mseg_wgrad_query) — launches nothing, so the
+// query IS the dispatch code, not a copy of its rules.  MSEG_KL: the call's main (matrix) kernel; MSEG_KL_AUX: helpers
+// (table initialisation, split-K reductions).  K is the kernel in parentheses, e.g. (igemm_halo_kernel<128, 1>).
+extern "C" void mseg_note_launch(const char* kernel, unsigned grid, unsigned block, int aux);
+extern "C" void mseg_dispatch_begin(int dry);
+extern "C" void mseg_dispatch_end(MsegKernelInfo* info);
+extern "C" void mseg_dispatch_note(int precision, size_t workspace);
+#define MSEG_KL(K, grid_, block_, shmem_, st_, ...)                                              \
+  do {                                                                                           \
+    mseg_note_launch(#K, (unsigned)(grid_).x, (unsigned)(block_).x, 0);                          \
+    if (!mseg_dispatch_dry()) hipLaunchKernelGGL(K, grid_, block_, shmem_, st_, ##__VA_ARGS__);    \
+  } while (0)
+#define MSEG_KL_AUX(K, grid_, block_, shmem_, st_, ...)                                          \
+  do {                                                                                           \
+    mseg_note_launch(#K, (unsigned)(grid_).x, (unsigned)(block_).x, 1);                          \
+    if (!mseg_dispatch_dry()) hipLaunchKernelGGL(K, grid_, block_, shmem_, st_, ##__VA_ARGS__);    \
   } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

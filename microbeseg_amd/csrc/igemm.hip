@@ -22,10 +22,10 @@
 // slab of packed weights from LDS (row stride 36 floats -> conflict-free ds_read_b128); raw global loads of step s+1 are
 // issued before the MFMAs of step s and consumed (activation, scale/shift, ds_write) after them.
 #include "common.h"
+#include "igemm_common.h"
 
-#define KC 32
-#define LDS_STRIDE 36
-#define MSEG_MAX_CH 8192
+// igemm_p8.hip: one 8-wave workgroup per CU with DMA-streamed weights (>= 128 output channels, bf16 tensors)
+int igemm_p8_try(const MsegIgemm& p, int tw_log2, int tr, int m_fastest, int cus, hipStream_t st, const char** name);
 
 // identity affine for operands that carry no scale/shift table: lets the K-loop load the tables unconditionally
 __device__ float g_ident_scale[MSEG_MAX_CH];
@@ -37,260 +37,6 @@ __global__ void init_ident_kernel() {
   }
 }
 
-template <int BM, int BN>
-struct IgemmCfg {
-  static constexpr int WM = (BN >= 128) ? 2 : 4;  // waves along M
-  static constexpr int WN = 4 / WM;               // waves along N
-  static constexpr int TM = BM / WM;              // per-wave rows   (multiple of 32)
-  static constexpr int TN = BN / WN;              // per-wave cols
-  static constexpr int MB = TM / 32;
-  static constexpr int NB = TN / 32;
-  static constexpr int AROWS = BM / 32;           // A rows staged per thread
-  static constexpr int BROWS = BN / 32;
-};
-
-struct RowInfo {
-  int n;    // image index, -1 = row beyond M
-  int oy, ox;
-};
-
-__device__ __forceinline__ RowInfo decode_row(const MsegIgemm& p, int m, int M) {
-  RowInfo r;
-  if (m >= M) { r.n = -1; r.oy = 0; r.ox = 0; return r; }
-  if (p.morder == MSEG_MORDER_PARITY) {
-    const int Hh = p.Ho >> 1, Wh = p.Wo >> 1;
-    const int per = p.NB * Hh * Wh;
-    const int cls = m / per;
-    int rem = m - cls * per;
-    r.n = rem / (Hh * Wh);
-    rem -= r.n * (Hh * Wh);
-    const int y2 = rem / Wh;
-    r.oy = 2 * y2 + (cls >> 1);
-    r.ox = 2 * (rem - y2 * Wh) + (cls & 1);
-  } else {
-    r.n = m / (p.Ho * p.Wo);
-    int rem = m - r.n * (p.Ho * p.Wo);
-    r.oy = rem / p.Wo;
-    r.ox = rem - r.oy * p.Wo;
-  }
-  return r;
-}
-
-// Tap geometry folded into three kernel-uniform integers so that the per-row code of the K-loop is straight-line:
-//   t = o * sm + dir * (k - pad);  live iff (t & sh) == 0;  source coordinate = t >> sh
-//   CONV : sm = stride, dir = +1, sh = 0          TCONV (transposed conv / dgrad): sm = 1, dir = -1, sh = stride >> 1
-struct TapGeom { int sm, dir, sh, pad, Hi, Wi; };
-
-__device__ __forceinline__ TapGeom make_geom(const MsegIgemm& p) {
-  TapGeom g;
-  const bool conv = p.mode == MSEG_MODE_CONV;
-  g.sm = conv ? p.stride : 1;
-  g.dir = conv ? 1 : -1;
-  g.sh = conv ? 0 : (p.stride >> 1);
-  g.pad = p.pad; g.Hi = p.Hi; g.Wi = p.Wi;
-  return g;
-}
-
-// source pixel of (row, tap); false if the tap falls outside the source / on a dead phase (no early exits)
-__device__ __forceinline__ bool tap_coord(const TapGeom& g, const RowInfo& r, int ky, int kx, int& iy, int& ix) {
-  const int ty = r.oy * g.sm + g.dir * (ky - g.pad);
-  const int tx = r.ox * g.sm + g.dir * (kx - g.pad);
-  iy = ty >> g.sh; ix = tx >> g.sh;                     // arithmetic shift: negative stays negative -> rejected below
-  return (r.n >= 0) & (((ty | tx) & g.sh) == 0) & (iy >= 0) & (iy < g.Hi) & (ix >= 0) & (ix < g.Wi);
-}
-
-// Gather kernels: first source pixel a tile of BM consecutive GEMM rows can touch (64-bit, wave-uniform).  The buffer
-// descriptors of a tile are based there, so the 32-bit offsets of its loads only span the few image rows the tile reads —
-// operands of any size (a 4096 x 4096 x 128 level-1 tensor is 8.6 GB) stay on the fast kernels.  Source pixels grow
-// monotonically with the GEMM row inside a tile (linear M-order, and parity M-order within one parity class), so the
-// first row's tap (0, 0), minus the reach of the mirrored taps of a transposed convolution, is a lower bound.
-__device__ __forceinline__ long long tile_base_pixel(const MsegIgemm& p, const TapGeom& g, int m0, int M) {
-  const RowInfo r = decode_row(p, m0, M);
-  const int iy0 = (r.oy * g.sm - g.dir * g.pad) >> g.sh, ix0 = (r.ox * g.sm - g.dir * g.pad) >> g.sh;
-  long long px = ((long long)r.n * p.Hi + iy0) * p.Wi + ix0;
-  if (g.dir < 0) px -= (long long)((p.KH - 1) >> g.sh) * p.Wi + ((p.KW - 1) >> g.sh);
-  return px;
-}
-
-// ---- shared epilogue ---------------------------------------------------------------------------------------------
-template <typename Cfg, typename AccT>
-__device__ __forceinline__ void igemm_epilogue(AccT& acc /* f32x16[MB][NB] */, int m0, int n0, int wm, int wn,
-                                               int lane, int M, int tw_log2 = -1, int img2 = 0, int oy0 = 0,
-                                               int ox0 = 0) {
-  const int li = lane & 31, lh = lane >> 5;
-  // The epilogue-only fields are re-read from kernarg memory here (opaque pointer) so that they do not occupy
-  // SGPRs during the K-loop (the whole descriptor live = SGPR spills reloaded every iteration).
-  const MsegIgemm* pe = (const MsegIgemm*)__builtin_amdgcn_kernarg_segment_ptr();  // kernel argument 0
-  asm volatile("" : "+s"(pe));
-  const float* e_bias = pe->bias;
-  float* e_dst0 = pe->dst0;
-  float* e_dst1 = pe->dst1;
-  const int e_epi = pe->epi, e_split = pe->split, e_ld0 = pe->ld0, e_ld1 = pe->ld1, e_acc0 = pe->acc0,
-            e_acc1 = pe->acc1, e_Cq = pe->Cq, e_morder = pe->morder, e_Ho = pe->Ho, e_Wo = pe->Wo, e_Ngemm = pe->Ngemm;
-  const bool e_d16 = pe->dst_dtype == MSEG_ST_BF16;   // destinations stored as bf16 (round to nearest even on store)
-#pragma unroll
-  for (int b = 0; b < Cfg::NB; ++b) {
-    const int n = n0 + wn * Cfg::TN + b * 32 + li;
-    const bool nvalid = n < e_Ngemm;
-    float bias = 0.f;
-    float* dst = e_dst0;
-    int ld = e_ld0, noff = n, accf = e_acc0;
-    int sa = 0, sb = 0;
-    if (e_epi == MSEG_EPI_SCATTER2X2) {
-      const int ab = nvalid ? n / e_Cq : 0;
-      const int co = n - ab * e_Cq;
-      sa = ab >> 1; sb = ab & 1;
-      noff = co;
-      if (e_bias && nvalid) bias = e_bias[co];
-    } else {
-      if (n >= e_split) { dst = e_dst1; ld = e_ld1; noff = n - e_split; accf = e_acc1; }
-      if (e_bias && nvalid) bias = e_bias[n];
-    }
-#pragma unroll
-    for (int a = 0; a < Cfg::MB; ++a) {
-      // Row addressing.  The 32 rows of one MFMA tile are consecutive GEMM rows; the destination element of row `row` is
-      // tbase + rel(row), with everything that needs a division decoded ONCE per tile (wave-uniform) and only adds /
-      // compares per row — per-element divisions are VALU work the short-K layers (ConvTranspose: K = Cin) cannot hide:
-      //   mode 0  affine: rel = row * step  (one image-row segment; plain linear order; 32 | row length of the scatter /
-      //           parity forms)
-      //   mode 1  halo kernel with pixel tiles narrower than 32: shifts and masks
-      //   mode 2  scatter (ConvTranspose) over rows that are no multiple of 32: column wraps by compare
-      //   mode 3  parity order (stride-2 data gradient) likewise, inside one parity class
-      //   mode 4  tile straddling two parity classes (generic kernel only): full decode per element
-      const int mb = m0 + wm * Cfg::TM + a * 32;
-      const int rows_left = (tw_log2 >= 0) ? 32 : M - mb;         // halo tiles never straddle the end of M
-      bool tile_ok = mb < M;
-      int mode = 0, step = 0;
-      size_t tbase = 0;
-      int b_img = 0, b_y = 0, b_x = 0, cls = 0;                  // decoded first row of the tile (modes 2, 3)
-      if (tw_log2 >= 0) {
-        const int i = wm * Cfg::TM + a * 32;
-        const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & ((1 << tw_log2) - 1));
-        tile_ok = oy < e_Ho;
-        tbase = ((size_t)(img2 * e_Ho + oy) * e_Wo + ox) * ld + noff;
-        step = ld;
-        mode = tw_log2 >= 5 ? 0 : 1;
-      } else if (e_epi == MSEG_EPI_SCATTER2X2) {
-        if (tile_ok) {
-          b_img = mb / (e_Ho * e_Wo);
-          const int rem = mb - b_img * (e_Ho * e_Wo);
-          b_y = rem / e_Wo; b_x = rem - b_y * e_Wo;
-          tbase = (((size_t)b_img * (2 * e_Ho) + 2 * b_y + sa) * (2 * e_Wo) + 2 * b_x + sb) * e_Cq + noff;
-          step = 2 * e_Cq;
-          mode = (e_Wo & 31) == 0 ? 0 : 2;
-        }
-      } else if (e_morder == MSEG_MORDER_PARITY) {
-        if (tile_ok) {
-          const int Hh = e_Ho >> 1, Wh = e_Wo >> 1, per = (M >> 2);
-          cls = mb / per;
-          const int rem = mb - cls * per;
-          b_img = rem / (Hh * Wh);
-          const int r2 = rem - b_img * (Hh * Wh);
-          b_y = r2 / Wh; b_x = r2 - b_y * Wh;
-          tbase = (((size_t)b_img * e_Ho + 2 * b_y + (cls >> 1)) * e_Wo + 2 * b_x + (cls & 1)) * ld + noff;
-          step = 2 * ld;
-          mode = (Wh & 31) == 0 ? 0 : (rem + 31 < per ? 3 : 4);
-        }
-      } else {
-        tbase = (size_t)mb * ld + noff;
-        step = ld;
-      }
-      if (!nvalid || !tile_ok) continue;
-      const unsigned BAD = 0xffffffffu;
-      // element offset of `row` relative to tbase, or BAD — one closure per mode, selected by a wave-uniform branch
-      // OUTSIDE the row loops (a mode switch inside them is if-converted into selects that every row pays for)
-      auto rel_affine = [&](int row) -> unsigned { return row < rows_left ? (unsigned)(row * step) : BAD; };
-      auto rel_narrow = [&](int row) -> unsigned {
-        const int i0 = wm * Cfg::TM + a * 32, i = i0 + row;
-        const int dy = (i >> tw_log2) - (i0 >> tw_log2), dx = (i & ((1 << tw_log2) - 1)) - (i0 & ((1 << tw_log2) - 1));
-        if (oy0 + (i >> tw_log2) >= e_Ho) return BAD;
-        return (unsigned)((dy * e_Wo + dx) * ld);
-      };
-      // modes 2 / 3: walk `row` pixels to the right inside a (rows x W) grid of W = Wo (scatter) or Wo / 2 (parity)
-      auto rel_walk = [&](int row) -> unsigned {
-        if (row >= rows_left) return BAD;
-        const int Wg = mode == 2 ? e_Wo : (e_Wo >> 1), Hg = mode == 2 ? e_Ho : (e_Ho >> 1);
-        int x = b_x + row, y = b_y, img = b_img;
-        while (x >= Wg) { x -= Wg; ++y; }                         // <= 2 trips for rows of >= 16 pixels
-        while (y >= Hg) { y -= Hg; ++img; }
-        const long long d = mode == 2
-            ? ((((long long)(img - b_img) * (2 * e_Ho) + 2 * (y - b_y)) * (2 * e_Wo)) + 2 * (x - b_x)) * e_Cq
-            : (((long long)(img - b_img) * e_Ho + 2 * (y - b_y)) * e_Wo + 2 * (x - b_x)) * ld;
-        return (unsigned)d;                                        // a 32-row tile spans a few image rows: fits 32 bits
-      };
-      // all read-modify-write loads first, then all stores: a load/store pair per element would serialise 16 memory round
-      // trips (same pointer, the compiler may not reorder them), which short-K layers cannot hide
-      auto emit = [&](auto rel) {
-        if (e_d16) {
-          // bf16 destination: a lane holds ONE channel of 16 rows, i.e. 2-byte stores.  Lanes 2k / 2k+1 (channels n, n+1;
-          // bf16 storage has even channel counts) swap half of their values through a DPP quad permute, so that the even
-          // lane stores the channel PAIR of the even accumulator rows and the odd lane that of the odd rows: 8 dword
-          // stores (and 8 dword read-modify-write loads) per lane instead of 16 short ones.
-          const bool odd = li & 1;
-          __bf16* const d = reinterpret_cast<__bf16*>(dst) + (tbase - (odd ? 1 : 0));     // first channel of the pair
-          unsigned oldw[8], ro[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int r = 2 * q + (odd ? 1 : 0);
-            ro[q] = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
-            oldw[q] = 0u;
-          }
-          if (accf) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (ro[q] != BAD) oldw[q] = *reinterpret_cast<const unsigned*>(d + ro[q]);
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float mine_e = acc[a][b][2 * q] + bias, mine_o = acc[a][b][2 * q + 1] + bias;
-            // the even lane keeps row 2q and hands row 2q+1 to its neighbour; the odd lane the other way round
-            const float give = odd ? mine_e : mine_o, keep = odd ? mine_o : mine_e;
-            const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
-            const float lo = (odd ? got : keep) + bf16_lo(oldw[q]), hi = (odd ? keep : got) + bf16_hi(oldw[q]);
-            if (ro[q] != BAD) *reinterpret_cast<unsigned*>(d + ro[q]) = pack_bf16x2(lo, hi);
-          }
-          return;
-        }
-        float* const d = dst + tbase;
-        float old[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = 0.f;
-        if (accf) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
-            if (o != BAD) old[r] = d[o];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned o = rel((r & 3) + 8 * (r >> 2) + 4 * lh);
-          const float v = acc[a][b][r] + bias + old[r];   // (unconditional use: no read-modify-write load stays pending
-          if (o != BAD) d[o] = v;                         //  past the epilogue in the compiler's wait-count bookkeeping)
-        }
-      };
-      if (mode == 0) { emit(rel_affine); continue; }
-      if (mode == 1) { emit(rel_narrow); continue; }
-      if (mode != 4) { emit(rel_walk); continue; }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {                              // mode 4: parity tile across two classes
-        const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= M) continue;
-        const RowInfo ri = decode_row(*pe, m, M);
-        const size_t off = (((size_t)ri.n * e_Ho + ri.oy) * e_Wo + ri.ox) * ld + noff;
-        float v = acc[a][b][r] + bias;
-        if (e_d16) {
-          __bf16* const d = reinterpret_cast<__bf16*>(dst);
-          if (accf) v += (float)d[off];
-          d[off] = (__bf16)v;
-        } else {
-          if (accf) v += dst[off];
-          dst[off] = v;
-        }
-      }
-    }
-  }
-}
 
 template <int BM, int BN, bool PER_SAMPLE, bool GENERIC_ACT>
 __global__ __launch_bounds__(256) void igemm_kernel(const MsegIgemm p) {
@@ -2908,7 +2654,7 @@ extern "C" size_t mseg_igemm_workspace_bytes(const MsegIgemm* pp) {
   return (size_t)ks * p.NB * p.Hi * p.Wi * p.Ngemm * sizeof(float);
 }
 
-extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
+static int igemm_dispatch(const MsegIgemm* pp, void* stream) {
   if (!pp) return MSEG_EINVAL;
   const MsegIgemm& p = *pp;
   if (p.nsrc < 1 || p.nsrc > 2) return MSEG_EINVAL;
@@ -2947,14 +2693,18 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
   const long long M = (long long)p.NB * p.Ho * p.Wo;
   if (M <= 0 || M > 0x7fffffffLL) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  mseg_dispatch_note(p.precision, 0);
   // one-off, idempotent fill of the per-device identity tables (concurrent first calls write the same values)
   static bool ident_ready[64] = {false};
   int devid = 0;
-  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
-  if (!ident_ready[devid]) {
-    hipLaunchKernelGGL(init_ident_kernel, dim3(8), dim3(256), 0, st);
-    MSEG_LAUNCH_CHECK();
-    ident_ready[devid] = true;
+  const bool dry = mseg_dispatch_dry() != 0;          // a query: nothing is launched, no device is needed
+  if (!dry) {
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
+    if (!ident_ready[devid]) {
+      MSEG_KL_AUX(init_ident_kernel, dim3(8), dim3(256), 0, st);
+      MSEG_LAUNCH_CHECK();
+      ident_ready[devid] = true;
+    }
   }
   bool per_sample = false, generic = false;
   for (int i = 0; i < p.nsrc; ++i) {
@@ -3002,20 +2752,22 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       q.bias = nullptr;
       q.dst_dtype = MSEG_ST_F32;                       // partial sums stay fp32; the reduction rounds once
     }
+    mseg_dispatch_note(p.precision, ks > 1 ? need : 0);
     const dim3 hgrid((unsigned)(htiles * ks));
-#define MSEG_HALO(BN_, TR_) hipLaunchKernelGGL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
+#define MSEG_HALO(BN_, TR_) MSEG_KL((igemm_halo_kernel<BN_, TR_>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps)
     // weight tensor beyond ~2 MB (bf16) and several N tiles: pixel tiles fastest (see the kernel)
     const int m_fastest = ((long long)9 * p.Kpad * p.Ngemm * 2 > (2ll << 20)) && (p.Ngemm > BNv) ? 1 : 0;
 #define MSEG_HALO16(BN_, TR_)                                                                                          \
   do {                                                                                                                 \
-    if (s16) hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_, true>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest); \
-    else hipLaunchKernelGGL((igemm_halo_bf16_kernel<BN_, TR_, false>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest);    \
+    if (s16) MSEG_KL((igemm_halo_bf16_kernel<BN_, TR_, true>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest); \
+    else MSEG_KL((igemm_halo_bf16_kernel<BN_, TR_, false>), hgrid, dim3(512), 0, st, q, tw_log2, ks, cps, m_fastest);    \
   } while (0)
 #define MSEG_HALO16W4(TR_)                                                                                             \
   do {                                                                                                                 \
-    if (s16) hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, true>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);    \
-    else hipLaunchKernelGGL((igemm_halo_bf16w4_kernel<TR_, false>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);       \
+    if (s16) MSEG_KL((igemm_halo_bf16w4_kernel<TR_, true>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);    \
+    else MSEG_KL((igemm_halo_bf16w4_kernel<TR_, false>), hgrid, dim3(256), 0, st, q, tw_log2, ks, cps, m_fastest);       \
   } while (0)
+    int p8rc = 0;
     if (p.precision == MSEG_PREC_BF16 && s16 && !wide && g_c64p_on && p.nsrc == 1 && p.Cin == 64 && p.Kpad == 64 &&
         ks == 1 && tw_log2 <= 5 && p.split >= p.Ngemm && htiles >= 4 * (long long)c64p_workgroups()) {
       // 64 -> 64 channels on bf16 tensors (level 0): persistent workgroups that keep the layer's weights in LDS
@@ -3023,8 +2775,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       const dim3 pgrid((unsigned)wgs);                      // htiles >= 4 per workgroup: every group has work
 #define MSEG_C64P(TR_)                                                                                                        \
   do {                                                                                                                         \
-    if (q.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_c64p_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles); \
-    else hipLaunchKernelGGL((igemm_c64p_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles);               \
+    if (q.dst_dtype == MSEG_ST_BF16) MSEG_KL((igemm_c64p_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles); \
+    else MSEG_KL((igemm_c64p_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, q, tw_log2, (int)htiles);               \
   } while (0)
       if (tr == 0) MSEG_C64P(0); else if (tr == 1) MSEG_C64P(1); else MSEG_C64P(2);
 #undef MSEG_C64P
@@ -3034,18 +2786,22 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       const dim3 mgrid((unsigned)halo512_tiles(p, tw_log2));
 #define MSEG_HALO512(TR_)                                                                                                      \
   do {                                                                                                                         \
-    if (s16) hipLaunchKernelGGL((igemm_halo_bf16m512_kernel<TR_, true>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);      \
-    else hipLaunchKernelGGL((igemm_halo_bf16m512_kernel<TR_, false>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);         \
+    if (s16) MSEG_KL((igemm_halo_bf16m512_kernel<TR_, true>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);      \
+    else MSEG_KL((igemm_halo_bf16m512_kernel<TR_, false>), mgrid, dim3(512), 0, st, q, tw_log2, 1, cps, 0);         \
   } while (0)
       if (tr == 0) MSEG_HALO512(0); else if (tr == 1) MSEG_HALO512(1); else MSEG_HALO512(2);
 #undef MSEG_HALO512
+    } else if (p.precision == MSEG_PREC_BF16 && wide && s16 && ks == 1 &&
+               (p8rc = igemm_p8_try(q, tw_log2, tr, m_fastest, c64p_workgroups(), st, nullptr)) != 0) {
+      // >= 128 output channels on bf16 tensors with at least one 256-pixel tile per CU: igemm_p8.hip
+      if (p8rc < 0) return p8rc;
     } else if (p.precision == MSEG_PREC_BF16 && wide && s16 && g_w4m_on && ks == 1 && tw_log2 >= 3 &&
                halo_big_tiles(p, tw_log2, 256) * ((p.Ngemm + 127) / 128) >= 2 * (long long)c64p_workgroups()) {
       // 128-channel tiles on enough pixels: 256-pixel tiles (fewer LDS reads and weight bytes per MFMA)
       const dim3 mgrid((unsigned)(halo_big_tiles(p, tw_log2, 256) * ((p.Ngemm + 127) / 128)));
       // (bf16 tensors only: with fp32 sources the 11 staging loads per thread do not fit beside 128 accumulator registers)
 #define MSEG_HALOW4M(TR_) \
-  hipLaunchKernelGGL((igemm_halo_bf16w4m_kernel<TR_, true>), mgrid, dim3(256), 0, st, q, tw_log2, 1, cps, m_fastest)
+  MSEG_KL((igemm_halo_bf16w4m_kernel<TR_, true>), mgrid, dim3(256), 0, st, q, tw_log2, 1, cps, m_fastest)
       if (tr == 0) MSEG_HALOW4M(0); else if (tr == 1) MSEG_HALOW4M(1); else MSEG_HALOW4M(2);
 #undef MSEG_HALOW4M
     } else if (p.precision == MSEG_PREC_BF16) {
@@ -3061,7 +2817,7 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       const size_t total = (size_t)M * (size_t)(p.Ngemm >> 2);
       size_t blocks = (total + 255) / 256;
       if (blocks > 16384) blocks = 16384;
-      hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p.ws, ks,
+      MSEG_KL_AUX(igemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p.ws, ks,
                          (size_t)M, p.Ngemm, p.bias, p.dst0, p.ld0, p.acc0, p.dst1, p.ld1, p.acc1,
                          p.split < p.Ngemm ? p.split : p.Ngemm, p.dst_dtype == MSEG_ST_BF16 ? 1 : 0);
       MSEG_LAUNCH_CHECK();
@@ -3078,8 +2834,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const int nt = (int)(M / 128);
 #define MSEG_CTP(TR_)                                                                                                \
   do {                                                                                                               \
-    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctp_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
-    else hipLaunchKernelGGL((igemm_ctp_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                     \
+    if (p.dst_dtype == MSEG_ST_BF16) MSEG_KL((igemm_ctp_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
+    else MSEG_KL((igemm_ctp_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                     \
   } while (0)
     if (tr == 0) MSEG_CTP(0); else if (tr == 1) MSEG_CTP(1); else MSEG_CTP(2);
 #undef MSEG_CTP
@@ -3096,8 +2852,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const int nt = (int)(M / 64);
 #define MSEG_CTP2(TR_)                                                                                               \
   do {                                                                                                               \
-    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctp2_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
-    else hipLaunchKernelGGL((igemm_ctp2_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                    \
+    if (p.dst_dtype == MSEG_ST_BF16) MSEG_KL((igemm_ctp2_bf16_kernel<TR_, true>), pgrid, dim3(512), 0, st, p, nt); \
+    else MSEG_KL((igemm_ctp2_bf16_kernel<TR_, false>), pgrid, dim3(512), 0, st, p, nt);                    \
   } while (0)
     if (tr == 0) MSEG_CTP2(0); else if (tr == 1) MSEG_CTP2(1); else MSEG_CTP2(2);
 #undef MSEG_CTP2
@@ -3110,8 +2866,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
       p.Hi == 2 * p.Ho && p.Wi == 2 * p.Wo && (M % 64) == 0 && M / 64 >= 4 * (long long)c64p_workgroups()) {
     // data gradient of the level-0 ConvTranspose2d(128 -> 64): persistent workgroups with resident weights
     const dim3 pgrid((unsigned)c64p_workgroups());
-    if (p.dst_dtype == MSEG_ST_BF16) hipLaunchKernelGGL((igemm_ctd_bf16_kernel<true>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
-    else hipLaunchKernelGGL((igemm_ctd_bf16_kernel<false>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
+    if (p.dst_dtype == MSEG_ST_BF16) MSEG_KL((igemm_ctd_bf16_kernel<true>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
+    else MSEG_KL((igemm_ctd_bf16_kernel<false>), pgrid, dim3(512), 0, st, p, (int)(M / 64));
     MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }
@@ -3120,8 +2876,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const int tr = plain ? 0 : (generic ? 2 : 1);
 #define MSEG_FAST16_LAUNCH(BM_, BN_, TR_, PS_)                                                          \
   do {                                                                                                  \
-    if (s16) hipLaunchKernelGGL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p);   \
-    else hipLaunchKernelGGL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);      \
+    if (s16) MSEG_KL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p);   \
+    else MSEG_KL((igemm_fast_bf16_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);      \
   } while (0)
 #define MSEG_FAST16_TILE(BM_, BN_)                                                        \
   do {                                                                                    \
@@ -3143,8 +2899,8 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     const bool short_k = ((p.Cin + KC - 1) / KC) * live_taps <= 8;
 #define MSEG_FAST_LAUNCH(BM_, BN_, TR_, PS_)                                                              \
   do {                                                                                                    \
-    if (short_k) hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((igemm_fast_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);        \
+    if (short_k) MSEG_KL((igemm_fast_kernel<BM_, BN_, TR_, PS_, true>), grid, block, 0, st, p); \
+    else MSEG_KL((igemm_fast_kernel<BM_, BN_, TR_, PS_, false>), grid, block, 0, st, p);        \
   } while (0)
 #define MSEG_FAST_TILE(BM_, BN_)                                                          \
   do {                                                                                    \
@@ -3159,7 +2915,7 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
     return MSEG_OK;
   }
 #define MSEG_IGEMM_LAUNCH(BM_, BN_, PS_, GA_) \
-  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, PS_, GA_>), grid, block, 0, st, p)
+  MSEG_KL((igemm_kernel<BM_, BN_, PS_, GA_>), grid, block, 0, st, p)
   if (wide) {
     if (per_sample) { if (generic) MSEG_IGEMM_LAUNCH(128, 128, true, true); else MSEG_IGEMM_LAUNCH(128, 128, true, false); }
     else            { if (generic) MSEG_IGEMM_LAUNCH(128, 128, false, true); else MSEG_IGEMM_LAUNCH(128, 128, false, false); }
@@ -3170,6 +2926,22 @@ extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
 #undef MSEG_IGEMM_LAUNCH
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
+}
+
+extern "C" int mseg_igemm(const MsegIgemm* pp, void* stream) {
+  mseg_dispatch_begin(0);
+  const int rc = igemm_dispatch(pp, stream);
+  mseg_dispatch_end(nullptr);
+  return rc;
+}
+
+// the same dispatch with the launches switched off (common.h: MSEG_KL)
+extern "C" int mseg_igemm_query(const MsegIgemm* pp, MsegKernelInfo* info) {
+  if (!info) return MSEG_EINVAL;
+  mseg_dispatch_begin(1);
+  const int rc = igemm_dispatch(pp, nullptr);
+  mseg_dispatch_end(info);
+  return rc;
 }
 
 // ---- fp32 -> bf16 (round to nearest even) ------------------------------------------------------------------------------

@@ -1283,7 +1283,7 @@ extern "C" size_t mseg_wgrad_workspace_bytes(const MsegWgrad* pp) {
   return (size_t)splits * pp->KH * pp->KW * pp->P.C * pp->Nch * sizeof(float);
 }
 
-extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
+static int wgrad_dispatch(const MsegWgrad* pp, void* stream) {
   if (!pp) return MSEG_EINVAL;
   const MsegWgrad& p = *pp;
   if (wgrad_check(p) || !p.ws || !p.dst) return MSEG_EINVAL;
@@ -1292,6 +1292,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   const int T = p.KH * p.KW;
   const int tiles = ((p.P.C + 63) / 64) * ((p.Nch + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
+  mseg_dispatch_note(p.precision, (size_t)splits * T * p.P.C * p.Nch * sizeof(float));
   if (p.phase != 2) {
     const WgradSel sel = wgrad_select(p);
     const bool generic = sel.generic_act, per_sample = sel.per_sample;
@@ -1301,17 +1302,18 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
     if (sel.kind != 0) {
       static bool ident_ready[64] = {false};
       int devid = 0;
-      if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return MSEG_ELAUNCH;
-      if (!ident_ready[devid]) {
-        hipLaunchKernelGGL(wgrad_init_ident_kernel, dim3(1), dim3(64), 0, st);
+      const bool dry = mseg_dispatch_dry() != 0;      // a query: nothing is launched, no device is needed
+      if (!dry && (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64)) return MSEG_ELAUNCH;
+      if (!dry && !ident_ready[devid]) {
+        MSEG_KL_AUX(wgrad_init_ident_kernel, dim3(1), dim3(64), 0, st);
         MSEG_LAUNCH_CHECK();
         ident_ready[devid] = true;
       }
       if (sel.kind == 4) {                             // 3x3 stride-2 convolution (plain P)
 #define MSEG_WB4(T_, Q_)                                                                                          \
   do {                                                                                                            \
-    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
-    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
+    if (s16) MSEG_KL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
+    else MSEG_KL((wgrad_halo_bf16_kernel<T_, Q_, 2, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
   } while (0)
 #define MSEG_WB4_Q(T_) do { if (qtr == 0) MSEG_WB4(T_, 0); else if (qtr == 1) MSEG_WB4(T_, 1); else MSEG_WB4(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB4_Q(3); else MSEG_WB4_Q(2);
@@ -1321,8 +1323,8 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       } else if (sel.kind == 5) {                      // ConvTranspose2d 2x2 stride 2 (plain Q)
 #define MSEG_WB5(T_, P_)                                                                                          \
   do {                                                                                                            \
-    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, true>), grid, block, 0, st, p, splits, sps); \
-    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, false>), grid, block, 0, st, p, splits, sps);    \
+    if (s16) MSEG_KL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, true>), grid, block, 0, st, p, splits, sps); \
+    else MSEG_KL((wgrad_halo_bf16_kernel<T_, 0, 2, 2, P_, false>), grid, block, 0, st, p, splits, sps);    \
   } while (0)
 #define MSEG_WB5_P(T_) do { if (ptr == 0) MSEG_WB5(T_, 0); else if (ptr == 1) MSEG_WB5(T_, 1); else MSEG_WB5(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB5_P(3); else MSEG_WB5_P(2);
@@ -1332,8 +1334,8 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       } else if (sel.kind == 3) {
 #define MSEG_WB(T_, Q_)                                                                                           \
   do {                                                                                                            \
-    if (s16) hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
-    else hipLaunchKernelGGL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
+    if (s16) MSEG_KL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, true>), grid, block, 0, st, p, splits, sps); \
+    else MSEG_KL((wgrad_halo_bf16_kernel<T_, Q_, 1, 3, 0, false>), grid, block, 0, st, p, splits, sps);    \
   } while (0)
 #define MSEG_WB_Q(T_) do { if (qtr == 0) MSEG_WB(T_, 0); else if (qtr == 1) MSEG_WB(T_, 1); else MSEG_WB(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_WB_Q(3); else MSEG_WB_Q(2);
@@ -1341,21 +1343,21 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
 #undef MSEG_WB
         MSEG_LAUNCH_CHECK();
       } else if (sel.kind == 6) {
-#define MSEG_W9(T_, Q_) hipLaunchKernelGGL((wgrad_halo9_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_W9(T_, Q_) MSEG_KL((wgrad_halo9_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_W9_Q(T_) do { if (qtr == 0) MSEG_W9(T_, 0); else if (qtr == 1) MSEG_W9(T_, 1); else MSEG_W9(T_, 2); } while (0)
         if (tw_log2 == 3) MSEG_W9_Q(3); else MSEG_W9_Q(2);
 #undef MSEG_W9_Q
 #undef MSEG_W9
         MSEG_LAUNCH_CHECK();
       } else if (sel.kind == 2) {
-#define MSEG_WH(T_, Q_) hipLaunchKernelGGL((wgrad_halo_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WH(T_, Q_) MSEG_KL((wgrad_halo_kernel<T_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_WH_Q(T_) do { if (qtr == 0) MSEG_WH(T_, 0); else if (qtr == 1) MSEG_WH(T_, 1); else MSEG_WH(T_, 2); } while (0)
         if (tw_log2 == 5) MSEG_WH_Q(5); else if (tw_log2 == 4) MSEG_WH_Q(4); else if (tw_log2 == 3) MSEG_WH_Q(3); else MSEG_WH_Q(2);
 #undef MSEG_WH_Q
 #undef MSEG_WH
         MSEG_LAUNCH_CHECK();
       } else {
-#define MSEG_WF(KW_, P_, Q_) hipLaunchKernelGGL((wgrad_fast_kernel<KW_, P_, Q_>), grid, block, 0, st, p, splits, sps)
+#define MSEG_WF(KW_, P_, Q_) MSEG_KL((wgrad_fast_kernel<KW_, P_, Q_>), grid, block, 0, st, p, splits, sps)
 #define MSEG_WF_Q(KW_, P_) do { if (qtr == 0) MSEG_WF(KW_, P_, 0); else if (qtr == 1) MSEG_WF(KW_, P_, 1); else MSEG_WF(KW_, P_, 2); } while (0)
 #define MSEG_WF_P(KW_) do { if (ptr == 0) MSEG_WF_Q(KW_, 0); else if (ptr == 1) MSEG_WF_Q(KW_, 1); else MSEG_WF_Q(KW_, 2); } while (0)
       if (p.KW == 3) MSEG_WF_P(3); else MSEG_WF_P(2);
@@ -1365,7 +1367,7 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
       }
     } else {
 #define MSEG_WGRAD_LAUNCH(KW_, GA_, PS_) \
-  hipLaunchKernelGGL((wgrad_kernel<KW_, GA_, PS_>), grid, block, 0, st, p, splits, sps)
+  MSEG_KL((wgrad_kernel<KW_, GA_, PS_>), grid, block, 0, st, p, splits, sps)
     if (p.KW == 3) {
       if (generic) { if (per_sample) MSEG_WGRAD_LAUNCH(3, true, true); else MSEG_WGRAD_LAUNCH(3, true, false); }
       else         { if (per_sample) MSEG_WGRAD_LAUNCH(3, false, true); else MSEG_WGRAD_LAUNCH(3, false, false); }
@@ -1381,13 +1383,29 @@ extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
   // many splits (few channel tiles: the wide shallow levels) -> 16 thread groups share the split range
   if (splits >= 32) {
     const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 15) / 16);
-    hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
+    MSEG_KL_AUX((wgrad_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
                        p.P.C, p.Nch, p.Nch_store);
   } else {
     const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 63) / 64);
-    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
+    MSEG_KL_AUX((wgrad_reduce_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
                        p.P.C, p.Nch, p.Nch_store);
   }
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
+}
+
+extern "C" int mseg_wgrad(const MsegWgrad* pp, void* stream) {
+  mseg_dispatch_begin(0);
+  const int rc = wgrad_dispatch(pp, stream);
+  mseg_dispatch_end(nullptr);
+  return rc;
+}
+
+// the same dispatch with the launches switched off (common.h: MSEG_KL)
+extern "C" int mseg_wgrad_query(const MsegWgrad* pp, MsegKernelInfo* info) {
+  if (!info) return MSEG_EINVAL;
+  mseg_dispatch_begin(1);
+  const int rc = wgrad_dispatch(pp, nullptr);
+  mseg_dispatch_end(info);
+  return rc;
 }

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, NORM, MODE_CONV, MODE_TCONV, EPI_PLAIN, EPI_SCATTER2X2, MORDER_LINEAR, MORDER_PARITY,
-                   ST_F32, ST_BF16, MsegSrc, MsegIgemm, MsegWgrad, check)
+                   ST_F32, ST_BF16, MsegSrc, MsegIgemm, MsegWgrad, MsegKernelInfo, check)
 
 BN_EPS = 1e-5       # torch defaults used by the reference (unets.py:127-132)
 BN_MOMENTUM = 0.1
@@ -122,93 +122,6 @@ class KernelTimer:
 _timer = None
 
 
-def _tr_of(s):
-    if s.act == ACT["none"] and not s.scale:
-        return 0
-    return 1 if s.act in (ACT["none"], ACT["relu"]) else 2
-
-
-def _tile_span_ok(srcs, Hi, Wi, Ho, Wo, KH, stride):
-    """mirror of the launcher: the source rows one 128-pixel tile of a gather kernel reads must stay below 2 GiB (its
-    buffer descriptors are based per tile, so the size of the whole operand does not matter)"""
-    return all(((128 // Wo + 3) * stride + KH) * Wi * s.C * 4 < 0x7ffffff0 for s in srcs)
-
-
-def _halo_band_ok(srcs, Wi):
-    """mirror of the launcher: the halo kernels' descriptors span the <= 34 image rows of a tile's halo"""
-    return all(34 * Wi * s.C * 4 < 2 ** 31 for s in srcs)
-
-
-def _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm, halo_ok=False, parity_tiles=False, Ho=None,
-                       Wo=None, bf16_name=False):
-    """Name of the kernel instantiation mseg_igemm dispatches to (mirror of the launcher in csrc/igemm.hip), as it
-    appears in rocprofv3's kernel trace — so that bench.py's HIP-event averages can be compared row by row."""
-    bn = 128 if Ngemm > 64 else 64
-    per_sample = any(s.scale and s.ss != 0 for s in srcs)
-    generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in srcs)
-    common = KH <= 4 and KW <= 4 and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
-    fast = common and (mode == MODE_CONV or stride == 1 or parity_tiles) and \
-        _tile_span_ok(srcs, Hi, Wi, Ho or Hi, Wo or Wi, KH, stride)
-    # the halo kernel's buffer descriptors span a tile's row band: frames and batches of any size
-    if common and halo_ok and _halo_band_ok(srcs, Wi):
-        tr = max(_tr_of(s) for s in srcs)
-        return "igemm_halo_kernel<%d, %d>" % (bn, 0 if tr == 0 else (2 if generic else 1))
-    if fast:
-        tr = max(_tr_of(s) for s in srcs)
-        tr = 0 if tr == 0 else (2 if generic else 1)
-        # fp32 only: the single-LDS-stage form for launches of at most 8 K-steps (mirror of `short_k` in the launcher)
-        live = ((KH + 1) // 2) * ((KW + 1) // 2) if (mode == MODE_TCONV and stride == 2) else KH * KW
-        sb = ", true" if ((sum(s.C for s in srcs) + 31) // 32) * live <= 8 else ", false"
-        return "igemm_fast_kernel<128, %d, %d, %s%s>" % (bn, tr, "true" if (per_sample and tr) else "false",
-                                                        "" if bf16_name else sb)
-    return "igemm_kernel<128, %d, %s, %s>" % (bn, "true" if per_sample else "false", "true" if generic else "false")
-
-
-def _wgrad_halo_shape(Hp, Wp, Hq, Wq, KW, stride):
-    """mirror of wgrad_halo_shape in csrc/wgrad.hip"""
-    if not (KW == 3 and stride == 1 and Hq == Hp and Wq == Wp and Wp % 4 == 0):
-        return False
-    tw = 32
-    while Wp % tw:
-        tw //= 2
-    th = 32 // tw
-    return Hp * 5 >= ((Hp + th - 1) // th) * th * 4
-
-
-def _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride):
-    per_sample = any(s.scale and s.ss != 0 for s in [P] + list(Qs))
-    generic = any(s.act not in (ACT["none"], ACT["relu"]) for s in [P] + list(Qs))
-    halo = _wgrad_halo_shape(Hp, Wp, Hq, Wq, KW, stride) and _tr_of(P) == 0
-    concat_ok = len(Qs) == 1 or Qs[0].C % 64 == 0
-    halo = halo and concat_ok and Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)
-    fast = halo or (concat_ok and ((not per_sample) or (Hp * Wp) % 32 == 0) and NB * Hp * Wp * P.C * 4 < 2 ** 31 and
-                    all(NB * Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs))
-    if fast and halo:
-        tw9 = 3 if Wp % 8 == 0 else 2                 # all nine taps per workgroup on 4 x 8 / 8 x 4 pixel blocks
-        th9 = 32 >> tw9
-        if Hp * 5 >= ((Hp + th9 - 1) // th9) * th9 * 4:
-            return "wgrad_halo9_kernel<%d, %d>" % (tw9, max(_tr_of(s) for s in Qs))
-        twl = 5
-        while Wp % (1 << twl):
-            twl -= 1
-        return "wgrad_halo_kernel<%d, %d>" % (twl, max(_tr_of(s) for s in Qs))
-    if fast:
-        return "wgrad_fast_kernel<%d, %d, %d>" % (KW, _tr_of(P), max(_tr_of(s) for s in Qs))
-    return "wgrad_kernel<%d, %s, %s>" % (KW, "true" if generic else "false", "true" if per_sample else "false")
-
-
-def _halo_tile_efficient(Hi, Wi, max_tw=64):
-    """mirror of the launcher's rule: 128-pixel halo tiles (TW = largest power of two <= 64 (bf16 kernel: 32) dividing W)
-    are used only if at least 80 % (bf16 kernel: 50 %) of their rows fall inside the image"""
-    tw = max_tw
-    while Wi % tw:
-        tw //= 2
-    th = 128 // tw
-    if max_tw == 32:
-        return Hi * 2 >= ((Hi + th - 1) // th) * th
-    return Hi * 5 >= ((Hi + th - 1) // th) * th * 4
-
-
 def set_kernel_timer(t):
     global _timer
     _timer = t
@@ -218,9 +131,11 @@ _precision = "fp32"
 
 
 def set_precision(mode):
-    """'fp32' (default; the reference's arithmetic) or 'bf16' (BASELINE configs[2]): the 3x3 stride-1 convolutions —
-    forward, data gradient and weight gradient, i.e. the bulk of the FLOPs — round their (normalised) operands to bf16 for
-    the matrix cores and accumulate in fp32.  Tensors in HBM, normalisation statistics, loss and optimizer stay fp32."""
+    """'fp32' (default; the reference's arithmetic) or 'bf16' (BASELINE configs[2]): every convolution launch that has a
+    bf16 matrix-core kernel (mseg_igemm_query / mseg_wgrad_query answer that) rounds its (normalised) operands to bf16 and
+    accumulates in fp32; when ALL launches of a network have one, activations and activation gradients are also STORED as
+    bf16 (set_bf16_storage / bf16_storage_ok).  Weights, weight gradients, normalisation statistics, loss and
+    optimizer state stay fp32."""
     global _precision
     if mode not in ("fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -257,55 +172,63 @@ def set_bf16_storage(flag):
     _bf16_storage = bool(flag)
 
 
-class _Shape:
-    """stand-in for MsegSrc / PackedW in the dispatch mirrors below: only the fields those rules read"""
+_DUMMY = 256          # a non-null, 16-byte aligned "pointer" for dispatch queries (a query dereferences nothing)
 
-    def __init__(self, **kw):
-        self.__dict__.update(kw)
+
+def _dummy_src(c, dtype=ST_BF16):
+    s = MsegSrc()
+    s.ptr, s.C, s.dtype = _DUMMY, c, dtype
+    return s
+
+
+def _dummy_pack(n, k):
+    return (_round_up(n, 128), _round_up(k, 32))
 
 
 def bf16_storage_ok(spec, N, cin, H, W, training):
     """Can this network run with bf16 tensor storage?  The bf16-storage forms exist for the bf16 matrix-core kernels, the
     first-layer / head / normalisation kernels: every convolution launch of the forward pass (and, when a tape is kept, of
     the backward pass) must map to one of them, channel counts must be multiples of 8 (16-byte staging loads of 8 bf16),
-    and the first layer must take the VALU kernels.  Otherwise bf16 mode keeps fp32 tensors (operand rounding only)."""
+    and the first layer must take the VALU kernels.  Otherwise bf16 mode keeps fp32 tensors (operand rounding only).
+    Whether a launch has a bf16 kernel is the LIBRARY's answer (mseg_igemm_query / mseg_wgrad_query on the descriptor the
+    launch would carry, with bf16 operands and destinations), not a rule restated here."""
     if spec.pool_method == "max":
         return False
 
-    def src(c):
-        return _Shape(C=c, scale=None, ss=0, act=0)
+    def ig(cins, ngemm, nb, hi, wi, ho, wo, kh, kw, stride, pad, mode, epi=EPI_PLAIN, morder=MORDER_LINEAR, cq=0, taps=None):
+        npad, kpad = _dummy_pack(ngemm, sum(cins))
+        return igemm_query([_dummy_src(v) for v in cins], kpad, npad, nb, hi, wi, ho, wo, kh, kw, stride, pad, mode, ngemm,
+                           ld0=(cq if epi == EPI_SCATTER2X2 else ngemm), epi=epi, Cq=cq, morder=morder, precision="bf16",
+                           dst_dtype=ST_BF16) is not None
 
-    def pack(T, n, k):
-        return _Shape(Npad=_round_up(n, 128), Kpad=_round_up(k, 32))
+    def wg(pc, qcs, nb, hp, wp, hq, wq, kh, kw, stride, pad):
+        return wgrad_query(_dummy_src(pc), [_dummy_src(v) for v in qcs], nb, hp, wp, hq, wq, kh, kw, stride, pad,
+                           precision="bf16") is not None
 
     def conv_ok(cins, cout, hi, wi, stride):
         ho, wo = (hi + 2 - 3) // stride + 1, (wi + 2 - 3) // stride + 1
         c = sum(cins)
         if any(v % 8 for v in cins) or cout % 8:
             return False
-        if _bf16_launch([src(v) for v in cins], pack(9, cout, c), N, hi, wi, ho, wo, 3, 3, stride, 1, MODE_CONV, EPI_PLAIN,
-                        MORDER_LINEAR) is None:
+        if not ig(cins, cout, N, hi, wi, ho, wo, 3, 3, stride, 1, MODE_CONV):
             return False
         if training:
             morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
-            if _bf16_launch([src(cout)], pack(9, c, cout), N, ho, wo, hi, wi, 3, 3, stride, 1, MODE_TCONV, EPI_PLAIN,
-                            morder) is None:
+            if not ig([cout], c, N, ho, wo, hi, wi, 3, 3, stride, 1, MODE_TCONV, morder=morder):
                 return False
-            if _wgrad_bf16_ok(src(cout), [src(v) for v in cins], N, ho, wo, hi, wi, 3, 3, stride, 1) is None:
+            if not wg(cout, cins, N, ho, wo, hi, wi, 3, 3, stride, 1):
                 return False
         return True
 
     def up_ok(ci, co, hi, wi):
         if ci % 8 or co % 8:
             return False
-        if _bf16_launch([src(ci)], pack(1, 4 * co, ci), N, hi, wi, hi, wi, 1, 1, 1, 0, MODE_CONV, EPI_SCATTER2X2,
-                        MORDER_LINEAR) is None:
+        if not ig([ci], 4 * co, N, hi, wi, hi, wi, 1, 1, 1, 0, MODE_CONV, epi=EPI_SCATTER2X2, cq=co):
             return False
         if training:
-            if _bf16_launch([src(co)], pack(4, ci, co), N, 2 * hi, 2 * wi, hi, wi, 2, 2, 2, 0, MODE_CONV, EPI_PLAIN,
-                            MORDER_LINEAR) is None:
+            if not ig([co], ci, N, 2 * hi, 2 * wi, hi, wi, 2, 2, 2, 0, MODE_CONV):
                 return False
-            if _wgrad_bf16_ok(src(ci), [src(co)], N, hi, wi, 2 * hi, 2 * wi, 2, 2, 2, 0) is None:
+            if not wg(ci, [co], N, hi, wi, 2 * hi, 2 * wi, 2, 2, 2, 0):
                 return False
         return True
 
@@ -461,18 +384,67 @@ def repack_all(params):
     return len(entries)
 
 
-def _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, morder):
-    """which bf16 kernel a launch takes in bf16 mode: 'halo' (3x3 stride 1), 'fast' (the gather kernel: stride-2
-    convolutions, ConvTranspose as a GEMM, their data gradients) or None = stays fp32 (mirror of mseg_igemm's dispatch)"""
-    common = KH <= 4 and KW <= 4 and KH * KW * w.Npad * w.Kpad * 4 < 2 ** 31 and (len(srcs) == 1 or srcs[0].C % 32 == 0)
-    if not common:
-        return None
-    if (KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi and Wo == Wi and epi == EPI_PLAIN and
-            morder == MORDER_LINEAR and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32) and _halo_band_ok(srcs, Wi)):
-        return "halo"
-    fast = (mode == MODE_CONV or stride == 1 or (morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0)) and \
-        _tile_span_ok(srcs, Hi, Wi, Ho, Wo, KH, stride)
-    return "fast" if fast else None
+class KernelChoice:
+    """the library's answer to "which kernel does this launch take" (MsegKernelInfo)"""
+    __slots__ = ("name", "bf16", "launches", "grid", "block", "workspace")
+
+    def __init__(self, info):
+        self.name = info.name.decode()
+        self.bf16 = info.precision == 1
+        self.launches, self.grid, self.block, self.workspace = info.launches, info.grid, info.block, info.workspace
+
+    def __repr__(self):
+        return f"KernelChoice({self.name!r}, bf16={self.bf16}, grid={self.grid})"
+
+
+def _fill_igemm(p, srcs, kpad, npad, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, ld0, acc0, ld1, acc1, split, epi,
+                Cq, morder):
+    for i, s in enumerate(srcs):
+        p.src[i] = s
+    p.nsrc = len(srcs)
+    p.Cin = sum(s.C for s in srcs)
+    p.Kpad, p.Npad = kpad, npad
+    p.NB, p.Hi, p.Wi, p.Ho, p.Wo = NB, Hi, Wi, Ho, Wo
+    p.KH, p.KW, p.stride, p.pad, p.mode, p.morder = KH, KW, stride, pad, mode, morder
+    p.Ngemm, p.epi = Ngemm, epi
+    p.split = Ngemm if split is None else split
+    p.ld0, p.ld1, p.acc0, p.acc1, p.Cq = ld0, ld1, acc0, acc1, Cq
+
+
+def _query(fn, p):
+    info = MsegKernelInfo()
+    rc = fn(C.byref(p), C.byref(info))
+    return KernelChoice(info) if rc == 0 else None
+
+
+def igemm_query(srcs, kpad, npad, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, ld0, acc0=0, ld1=0, acc1=0,
+                split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, precision=None, dst_dtype=ST_F32, bias=True):
+    """mseg_igemm_query for a launch described by its shapes (placeholder pointers): the kernel the library would take, or
+    None when it has none for this descriptor (e.g. precision 'bf16' on a shape without a bf16 kernel)."""
+    p = MsegIgemm()
+    _fill_igemm(p, srcs, kpad, npad, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, ld0, acc0, ld1, acc1, split, epi, Cq,
+                morder)
+    p.w = p.dst0 = _DUMMY
+    p.dst1 = _DUMMY if (split is not None and split < Ngemm) else None
+    p.bias = _DUMMY if bias else None
+    p.precision = 1 if (precision or _precision) == "bf16" else 0
+    p.dst_dtype = dst_dtype
+    return _query(_lib.load().mseg_igemm_query, p)
+
+
+_bf16_ok_cache = {}     # launch signature -> does the library have a bf16 kernel for it (toggles of the ablation hooks
+                        # switch between kernels of one precision, never the answer to this)
+
+
+def _igemm_bf16_ok(p):
+    key = (p.nsrc, tuple((p.src[i].C, p.src[i].act, bool(p.src[i].scale), p.src[i].ss != 0, p.src[i].dtype)
+                         for i in range(p.nsrc)), p.Kpad, p.Npad, p.NB, p.Hi, p.Wi, p.Ho, p.Wo, p.KH, p.KW, p.stride, p.pad,
+           p.mode, p.morder, p.Ngemm, p.epi, p.split, p.ld0, p.ld1, p.acc0, p.acc1, p.Cq, p.dst_dtype, bool(p.bias))
+    ok = _bf16_ok_cache.get(key)
+    if ok is None:
+        p.precision = 1
+        ok = _bf16_ok_cache[key] = _query(_lib.load().mseg_igemm_query, p) is not None
+    return ok
 
 
 def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, dst0, ld0, acc0=0,
@@ -480,25 +452,18 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
           precision=None):
     lib = _lib.load()
     p = MsegIgemm()
-    bf16 = _bf16_launch(srcs, w, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, epi, morder) \
-        if (precision or _precision) == "bf16" else None
-    for i, s in enumerate(srcs):
-        p.src[i] = s
-    p.nsrc = len(srcs)
-    p.Cin = sum(s.C for s in srcs)
-    p.Kpad = w.Kpad
-    p.Npad = w.Npad
-    p.w = w.bf16().data_ptr() if bf16 else w.t.data_ptr()
-    p.precision = 1 if bf16 else 0
+    _fill_igemm(p, srcs, w.Kpad, w.Npad, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, ld0, acc0, ld1, acc1, split, epi,
+                Cq, morder)
+    p.w = w.t.data_ptr()
     p.dst_dtype = _st(dst0)                 # bf16 tensor storage: the C ABI accepts it for the bf16 kernels only
     p.bias = _ptr(bias)
     p.dst0 = dst0.data_ptr()
     p.dst1 = _ptr(dst1)
-    p.NB, p.Hi, p.Wi, p.Ho, p.Wo = NB, Hi, Wi, Ho, Wo
-    p.KH, p.KW, p.stride, p.pad, p.mode, p.morder = KH, KW, stride, pad, mode, morder
-    p.Ngemm, p.epi = Ngemm, epi
-    p.split = Ngemm if split is None else split
-    p.ld0, p.ld1, p.acc0, p.acc1, p.Cq = ld0, ld1, acc0, acc1, Cq
+    # bf16 mode: the launch runs on the bf16 matrix cores iff the library has a bf16 kernel for it (its dispatch, queried)
+    bf16 = (precision or _precision) == "bf16" and _igemm_bf16_ok(p)
+    if bf16:
+        p.w = w.bf16().data_ptr()
+    p.precision = 1 if bf16 else 0
     need = lib.mseg_igemm_workspace_bytes(C.byref(p))      # split-K scratch (small batches / deep levels only)
     if need:
         buf = _splitk_ws.get(dst0.device)
@@ -512,101 +477,14 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
-    name = _igemm_kernel_name(srcs, w, NB, Hi, Wi, KH, KW, stride, mode, Ngemm,
-                              halo_ok=(KH == 3 and KW == 3 and stride == 1 and pad == 1 and Ho == Hi
-                                       and Wo == Wi and epi == EPI_PLAIN and morder == MORDER_LINEAR
-                                       and Wi % 4 == 0 and _halo_tile_efficient(Hi, Wi, 32 if bf16 else 64)),
-                              parity_tiles=(morder == MORDER_PARITY and (NB * Ho * Wo) % 512 == 0), Ho=Ho, Wo=Wo,
-                              bf16_name=bool(bf16))
-    if bf16:
-        name = name.replace("igemm_halo_kernel<128, ", "igemm_halo_bf16w4_kernel<").replace(
-            "igemm_halo_kernel", "igemm_halo_bf16_kernel").replace("igemm_fast_kernel", "igemm_fast_bf16_kernel")
-        name = name[:-1] + (", true>" if srcs[0].dtype == ST_BF16 else ", false>")      # S16: bf16-stored operands
-        # 64 -> 64 channels on bf16 tensors with enough pixel tiles and no split-K: the persistent kernel (mirror of the
-        # launcher's rule in csrc/igemm.hip)
-        if name.startswith("igemm_halo_bf16_kernel<64") and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and \
-                p.Cin == 64 and w.Kpad == 64 and p.split >= Ngemm and need == 0:
-            tw = 32
-            while Wi % tw:
-                tw //= 2
-            th = 128 // tw
-            tiles = NB * ((Hi + th - 1) // th) * (Wi // tw)
-            if tiles >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-                tr = name.split(",")[1].strip()
-                name = "igemm_c64p_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
-        elif epi == EPI_SCATTER2X2 and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 128 and w.Kpad == 128 and \
-                Cq == 64 and Ngemm == 256 and not acc0 and Wi % 32 == 0 and (Hi * Wi) % 128 == 0 and \
-                NB * Hi * Wi // 128 >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-            # ConvTranspose2d(128 -> 64) of level 0 on bf16 tensors: the persistent kernel (mirror of the launcher's rule)
-            tr = name.split(",")[2].strip()
-            name = "igemm_ctp_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
-        elif epi == EPI_SCATTER2X2 and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 256 and w.Kpad == 256 and \
-                Cq == 128 and Ngemm == 512 and not acc0 and Wi >= 32 and (Hi * Wi) % 64 == 0 and \
-                torch.cuda.get_device_properties(dst0.device).multi_processor_count % 4 == 0 and \
-                NB * Hi * Wi // 64 >= torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-            # ConvTranspose2d(256 -> 128) of level 1 on bf16 tensors: weights resident per output position
-            tr = name.split(",")[2].strip()
-            name = "igemm_ctp2_bf16_kernel<%s, %s>" % (tr, "true" if _st(dst0) == ST_BF16 else "false")
-        elif epi == EPI_PLAIN and KH == 2 and KW == 2 and stride == 2 and pad == 0 and mode == MODE_CONV and \
-                morder == MORDER_LINEAR and srcs[0].dtype == ST_BF16 and len(srcs) == 1 and p.Cin == 64 and w.Kpad == 64 and \
-                Ngemm == 128 and p.split >= Ngemm and not acc0 and bias is None and srcs[0].act == ACT["none"] and \
-                not srcs[0].scale and Wo % 32 == 0 and (NB * Ho * Wo) % 64 == 0 and \
-                NB * Ho * Wo // 64 >= 4 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-            # data gradient of the level-0 ConvTranspose2d(128 -> 64) on bf16 tensors: the persistent kernel
-            name = "igemm_ctd_bf16_kernel<%s>" % ("true" if _st(dst0) == ST_BF16 else "false")
-        elif name.startswith("igemm_halo_bf16w4_kernel<") and srcs[0].dtype == ST_BF16 and need == 0 and Wi % 8 == 0:
-            # 128-channel tiles on bf16 tensors with enough pixels: 256-pixel tiles (mirror of the launcher's rule)
-            tw = 32 if Wi % 32 == 0 else (16 if Wi % 16 == 0 else 8)
-            th = 256 // tw
-            rows = (Hi + th - 1) // th * th
-            tiles = NB * (rows // th) * (Wi // tw) * ((Ngemm + 127) // 128)
-            if Hi * 5 >= rows * 4 and tiles >= 2 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-                name = name.replace("igemm_halo_bf16w4_kernel<", "igemm_halo_bf16w4m_kernel<")
-        elif name.startswith("igemm_halo_bf16_kernel<64") and p.Cin >= 128 and need == 0 and Wi % 16 == 0:
-            # few output channels, many input channels (the 128 -> 64 concat convolutions): 512-pixel tiles
-            tw = 32 if Wi % 32 == 0 else 16
-            th = 512 // tw
-            rows = (Hi + th - 1) // th * th
-            tiles = NB * (rows // th) * (Wi // tw)
-            if Hi * 5 >= rows * 4 and tiles >= 2 * torch.cuda.get_device_properties(dst0.device).multi_processor_count:
-                tr = name.split(",")[1].strip()
-                name = "igemm_halo_bf16m512_kernel<%s, %s>" % (tr, "true" if srcs[0].dtype == ST_BF16 else "false")
-    e0, e1 = _timer.bracket(name, flops)
+    choice = _query(lib.mseg_igemm_query, p)               # the kernel's name as rocprofv3 prints it
+    e0, e1 = _timer.bracket(choice.name if choice else "igemm?", flops)
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
 
 
-def _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad):
-    """does this weight gradient take a bf16 kernel in bf16 mode?  (mirror of wgrad_select in csrc/wgrad.hip)
-    Returns the kernel's name in a rocprofv3 trace, or None = the launch stays fp32."""
-    if Wp % 4 or NB * Hp * Wp + 2048 * 32 >= 2 ** 31 - 1:
-        return None
-    if not (Hp * Wp * P.C * 4 < 2 ** 31 and all(Hq * Wq * s.C * 4 < 2 ** 31 for s in Qs)):
-        return None
-    twl = 3 if Wp % 8 == 0 else 2
-    qtr = max(_tr_of(s) for s in Qs)
-    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Hq == Hp and Wq == Wp and _tr_of(P) == 0:
-        th = 64 >> twl
-        if Hp * 2 < ((Hp + th - 1) // th) * th or (len(Qs) > 1 and Qs[0].C % 64):
-            return None
-        return "wgrad_halo_bf16_kernel<%d, %d, 1, 3, 0>" % (twl, qtr)
-    if stride == 2 and Hq == 2 * Hp and Wq == 2 * Wp and len(Qs) == 1:
-        th = 32 >> twl
-        if Hp * 2 < ((Hp + th - 1) // th) * th:
-            return None
-        if KH == 3 and KW == 3 and pad == 1 and _tr_of(P) == 0:
-            return "wgrad_halo_bf16_kernel<%d, %d, 2, 3, 0>" % (twl, qtr)
-        if KH == 2 and KW == 2 and pad == 0 and qtr == 0:
-            return "wgrad_halo_bf16_kernel<%d, 0, 2, 2, %d>" % (twl, _tr_of(P))
-    return None
-
-
-def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None, precision=None):
-    lib = _lib.load()
-    p = MsegWgrad()
-    bf16 = _wgrad_bf16_ok(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad) if (precision or _precision) == "bf16" else None
-    p.precision = 1 if bf16 else 0
+def _fill_wgrad(p, P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, nch_store):
     p.P = P
     for i, s in enumerate(Qs):
         p.Q[i] = s
@@ -616,6 +494,38 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
     p.NB, p.Hp, p.Wp, p.Hq, p.Wq = NB, Hp, Wp, Hq, Wq
     p.KH, p.KW, p.stride, p.pad = KH, KW, stride, pad
     p.splits = 0
+
+
+def wgrad_query(P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, nch_store=None, precision=None):
+    """mseg_wgrad_query: the weight-gradient kernel the library would take for these operands, or None."""
+    p = MsegWgrad()
+    _fill_wgrad(p, P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, nch_store)
+    p.precision = 1 if (precision or _precision) == "bf16" else 0
+    p.dst = p.ws = _DUMMY
+    p.phase = 1
+    return _query(_lib.load().mseg_wgrad_query, p)
+
+
+def _wgrad_bf16_ok(p):
+    key = ((p.P.C, p.P.act, bool(p.P.scale), p.P.ss != 0, p.P.dtype),
+           tuple((p.Q[i].C, p.Q[i].act, bool(p.Q[i].scale), p.Q[i].ss != 0, p.Q[i].dtype) for i in range(p.nq)),
+           p.Nch_store, p.NB, p.Hp, p.Wp, p.Hq, p.Wq, p.KH, p.KW, p.stride, p.pad)
+    ok = _bf16_ok_cache.get(key)
+    if ok is None:
+        q = MsegWgrad()
+        C.memmove(C.byref(q), C.byref(p), C.sizeof(MsegWgrad))
+        q.precision, q.phase = 1, 1
+        q.dst = q.ws = _DUMMY
+        ok = _bf16_ok_cache[key] = _query(_lib.load().mseg_wgrad_query, q) is not None
+    return ok
+
+
+def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=None, precision=None):
+    lib = _lib.load()
+    p = MsegWgrad()
+    _fill_wgrad(p, P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, nch_store)
+    bf16 = (precision or _precision) == "bf16" and _wgrad_bf16_ok(p)
+    p.precision = 1 if bf16 else 0
     p.dst = dst.data_ptr()
     need = lib.mseg_wgrad_workspace_bytes(C.byref(p))
     if need == 0:
@@ -625,11 +535,9 @@ def wgrad(P, Qs, dst, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, ws, nch_store=Non
         check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
         return
     flops = 2.0 * NB * Hp * Wp * P.C * p.Nch_store * KH * KW
-    name = _wgrad_kernel_name(P, Qs, NB, Hp, Wp, Hq, Wq, KW, stride)
-    if bf16:
-        name = bf16[:-1] + (", true>" if P.dtype == ST_BF16 else ", false>")
-    e0, e1 = _timer.bracket(name, flops)
     p.phase = 1     # split-K partial kernel only (timed) ...
+    choice = _query(lib.mseg_wgrad_query, p)
+    e0, e1 = _timer.bracket(choice.name if choice else "wgrad?", flops)
     e0.record()
     check(lib.mseg_wgrad(C.byref(p), _stream()), "wgrad")
     e1.record()

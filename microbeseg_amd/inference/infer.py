@@ -62,13 +62,15 @@ class InferWorker(QObject):
     # [extension] edge length of the tiles of sliding-window inference (``sliding_window=True``; inference/tiling.py)
     tile_size = 2048
 
-    def __init__(self, img_id_list=None, inference_path=None, user=None, pw=None, host=None, port=None, group_id=None,
+    def __init__(self, img_id_list=None, inference_path=None, omero_username=None, omero_password=None, omero_host=None,
+                 omero_port=None, group_id=None,
                  model=None, device='cuda:0', ths=(0.10, 0.45), channel=0, upload=True, overwrite=True,
                  sliding_window=False, print_output=False):
         super().__init__()
         self.img_id_list = img_id_list
         self.inference_path = inference_path
-        self.omero = dict(user=user, pw=pw, host=host, port=port, group_id=group_id)
+        self.omero_username, self.omero_password = omero_username, omero_password   # names: reference infer.py:30,66-69
+        self.omero_host, self.omero_port, self.group_id = omero_host, omero_port, group_id
         self.model = model
         self.device = torch.device(device)
         self.ths = list(ths)           # [th_cell, th_seed] (infer.py:362-365)

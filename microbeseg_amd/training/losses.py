@@ -109,6 +109,17 @@ def _allreduce_dice(sums, total):
     return allreduce_dice_sums(sums, total)
 
 
+def dice_loss(y_pred, y_true, use_sigmoid=True):
+    """Dice loss of ONE output channel (reference losses.py:40-68): 1 - (2 sum(g p) + 1) / (sum(g^2) + sum(p^2) + 1), p = the
+    prediction (through a sigmoid when ``use_sigmoid``), g = the ground truth, sums over the whole batch.  Not called by
+    the training path (the reference's ``ce_dice`` carries its own per-class form, :71-97 -> the fused kernel below);
+    kept for callers of the module's public surface.  Device tensors only, like every loss here."""
+    _require_cuda(y_pred, "dice_loss")
+    p = (torch.sigmoid(y_pred) if use_sigmoid else y_pred).reshape(-1)
+    g = y_true.reshape(-1).to(p.dtype)
+    return 1 - (2. * torch.dot(g, p) + 1.) / (torch.dot(g, g) + torch.dot(p, p) + 1.)
+
+
 def ce_dice(y_pred, y_true, num_classes=3):
     """Sum of cross-entropy and channel-wise Dice loss (reference losses.py:71-97), logits [N,3,H,W], labels [N,H,W]."""
     _require_cuda(y_pred, "ce_dice")

@@ -34,8 +34,10 @@ class FusedAdam(Optimizer):
         if weight_decay != 0 or not amsgrad:
             raise ValueError("FusedAdam implements the reference's configuration only: amsgrad=True, weight_decay=0")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
-        self._groups = []       # per param group: (params, flat p, g, m, v, vmax)
-        for group in self.param_groups:
+        # per param group: (index into self.param_groups, params, arenas, length).  The INDEX, not the dict:
+        # load_state_dict replaces the group dicts, and schedulers edit the ones in self.param_groups
+        self._groups = []
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
             if not ps:
                 continue
@@ -58,12 +60,13 @@ class FusedAdam(Optimizer):
                     p.grad = fg[o:o + k].view_as(p)
                     p.__dict__["_mseg_grad_direct"] = True     # engine.backward writes the gradient in place
                     p.__dict__["_mseg_grad_fresh"] = True      # ... once per zero_grad()
+                    p.__dict__["_mseg_grad_ver"] = p.grad._version
                     st = self.state[p]
                     st["step"] = 0
                     st["exp_avg"] = fm[o:o + k].view_as(p)
                     st["exp_avg_sq"] = fv[o:o + k].view_as(p)
                     st["max_exp_avg_sq"] = fx[o:o + k].view_as(p)
-            self._groups.append((group, ps, flat, n))
+            self._groups.append((gi, ps, flat, n))
 
     def zero_grad(self, set_to_none=True):
         """The gradient arena is persistent: the next backward overwrites it (set_to_none semantics without the frees)."""
@@ -72,9 +75,11 @@ class FusedAdam(Optimizer):
                 p.__dict__["_mseg_grad_fresh"] = True
                 if p.grad is None:                 # somebody dropped the view: restore it
                     raise RuntimeError("FusedAdam: p.grad was replaced; gradients must stay views of the arena")
+                p.__dict__["_mseg_grad_ver"] = p.grad._version
 
     def load_state_dict(self, state_dict):
-        """values are copied INTO the arenas (the state tensors must stay views of them)"""
+        """values are copied INTO the arenas (the state tensors must stay views of them); a state dict without moments
+        (a fresh torch.optim.Adam, or one saved before its first step) leaves the arenas at their current values"""
         views = {id(p): dict(self.state[p]) for _, ps, _, _ in self._groups for p in ps}
         super().load_state_dict(state_dict)
         with torch.no_grad():
@@ -82,9 +87,10 @@ class FusedAdam(Optimizer):
                 for p in ps:
                     new, old = self.state[p], views[id(p)]
                     for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
-                        old[key].copy_(new[key])
+                        if key in new:
+                            old[key].copy_(new[key])
                         new[key] = old[key]
-                    new["step"] = int(new["step"])
+                    new["step"] = int(new.get("step", old["step"]))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -95,7 +101,18 @@ class FusedAdam(Optimizer):
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
         from .. import engine
-        for group, ps, (fp, fg, fm, fv, fx), n in self._groups:
+        for gi, ps, (fp, fg, fm, fv, fx), n in self._groups:
+            group = self.param_groups[gi]                # looked up per step: lr schedulers / load_state_dict edit THESE
+            # written since zero_grad(): by the engine's backward (raw pointers: it clears the flag) or in place by the caller
+            # (p.grad.copy_(...): the tensor's version counter moves)
+            stale = [p for p in ps if p.__dict__.get("_mseg_grad_fresh") and
+                     p.grad._version == p.__dict__.get("_mseg_grad_ver")]
+            if stale:
+                # nobody has written these gradients since zero_grad(): the one launch below updates the whole arena,
+                # so (unlike torch.optim.Adam, which skips parameters without a gradient) it would re-apply the previous
+                # step's values.  The networks of this path always produce every gradient; anything else is a bug upstream.
+                raise RuntimeError(f"FusedAdam.step(): {len(stale)} of {len(ps)} parameters received no gradient since "
+                                   "zero_grad() (step() without backward, or an unused parameter)")
             step = self.state[ps[0]]["step"] + 1
             b1, b2 = group["betas"]
             _lib.check(lib.mseg_adam_amsgrad_step(fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr(),

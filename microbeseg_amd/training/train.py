@@ -406,6 +406,12 @@ class TrainWorker(QObject):
             except RuntimeError as err:
                 if not is_out_of_memory(err):
                     raise
+                out_of_memory = True
+            else:
+                out_of_memory = False
+            if out_of_memory:
+                # outside the handler: `err` (whose traceback pins the failed attempt's frames) is gone, the cyclic collector
+                # frees the network / optimizer arenas / packed weights of that attempt, and only then is the cache emptied
                 text = ladder.step_down()
                 if ladder.exhausted:
                     if print_output:
@@ -413,6 +419,8 @@ class TrainWorker(QObject):
                     self.text_output_main_gui.emit(text)
                     self.text_output.emit('Stop training due to memory problems')
                 self.text_output_main_gui.emit(text)
+                datasets = None
+                gc.collect()
                 if torch.cuda.is_available():
                     torch.cuda.empty_cache()
                 if ladder.exhausted:

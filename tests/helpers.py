@@ -49,20 +49,39 @@ def grad_floor(fx, prefix="g/"):
 
 
 def bf16_rule(kind, xs, ws):
-    """which of (forward, data gradient, weight gradient) of a layer the engine runs with bf16 operands: mirror of
-    engine._bf16_launch / engine._wgrad_bf16_ok for the shapes of this test (first layer: VALU kernels, fp32)"""
+    """which of (forward, data gradient, weight gradient) of a layer run with bf16 operands in bf16 mode: the LIBRARY's
+    answer for the three launches of that layer (engine.igemm_query / wgrad_query = mseg_igemm_query / mseg_wgrad_query;
+    concat inputs are asked as one source, which the dispatch treats alike; first layer: VALU kernels, fp32)"""
+    from microbeseg_amd import engine as E
+    from microbeseg_amd._lib import ST_F32
     N, cin, H, W = xs
 
-    def rows_ok(h, w, pix):                               # pixel blocks of the bf16 weight-gradient kernel
-        th = pix // (8 if w % 8 == 0 else 4)
-        return w % 4 == 0 and h * 2 >= ((h + th - 1) // th) * th
-    if kind == "up":                                      # P = the layer's input (H x W)
-        return (True, True, rows_ok(H, W, 32))
-    if kind == "pool":                                    # P = dz (H/2 x W/2); data gradient: whole 128-row parity tiles
-        return (True, (N * H * W) % 512 == 0, H % 2 == 0 and W % 2 == 0 and rows_ok(H // 2, W // 2, 32))
+    def src(c):
+        return E._dummy_src(c, ST_F32)
+
+    def ig(c_in, ngemm, hi, wi, ho, wo, k, stride, pad, mode, **kw):
+        npad, kpad = E._dummy_pack(ngemm, c_in)
+        return E.igemm_query([src(c_in)], kpad, npad, N, hi, wi, ho, wo, k, k, stride, pad, mode, ngemm, precision="bf16",
+                             **kw) is not None
+
+    def wg(pc, qc, hp, wp, hq, wq, k, stride, pad):
+        return E.wgrad_query(src(pc), [src(qc)], N, hp, wp, hq, wq, k, k, stride, pad, precision="bf16") is not None
+    if kind == "up":                                      # ConvTranspose2d 2x2 stride 2, weight (Cin, Cout, 2, 2)
+        co = ws[1]
+        return (ig(cin, 4 * co, H, W, H, W, 1, 1, 0, E.MODE_CONV, ld0=co, epi=E.EPI_SCATTER2X2, Cq=co),
+                ig(co, cin, 2 * H, 2 * W, H, W, 2, 2, 0, E.MODE_CONV, ld0=cin, bias=False),
+                wg(cin, co, H, W, 2 * H, 2 * W, 2, 2, 0))
+    cout = ws[0]
     if cin <= 4:
         return (False, False, False)
-    return (True, True, rows_ok(H, W, 64))   # forward / data gradient: halo kernel, or the gather kernel where it does not tile
+    if kind == "pool":                                    # 3x3 stride 2
+        ho, wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        return (ig(cin, cout, H, W, ho, wo, 3, 2, 1, E.MODE_CONV, ld0=cout),
+                ig(cout, cin, ho, wo, H, W, 3, 2, 1, E.MODE_TCONV, ld0=cin, morder=E.MORDER_PARITY, bias=False),
+                wg(cout, cin, ho, wo, H, W, 3, 2, 1))
+    return (ig(cin, cout, H, W, H, W, 3, 1, 1, E.MODE_CONV, ld0=cout),
+            ig(cout, cin, H, W, H, W, 3, 1, 1, E.MODE_TCONV, ld0=cin, bias=False),
+            wg(cout, cin, H, W, H, W, 3, 1, 1))
 
 
 class NodeTrace:

@@ -196,7 +196,7 @@ def test_conv3x3_wgrad_all_taps_kernel(eng, N, Cin, Cout, H, W, act, per_sample,
     qs = [n.src() for n in nodes]          # MsegSrc holds raw pointers: the nodes must outlive the launch
     dz = nhwc(gy).cuda()
     P = eng.plain_src(dz, Cout)
-    assert eng._wgrad_kernel_name(P, qs, N, H, W, H, W, 3, 1).startswith("wgrad_halo9_kernel<%d" % (3 if W % 8 == 0 else 2))
+    assert eng.wgrad_query(P, qs, N, H, W, H, W, 3, 3, 1, 1).name.startswith("wgrad_halo9_kernel<%d" % (3 if W % 8 == 0 else 2))
     dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
     eng.wgrad(P, qs, dW, N, H, W, H, W, 3, 3, 1, 1, eng.Workspace(torch.device("cuda")))
     assert rel_err(dW.cpu(), w.grad) < TOL
@@ -470,7 +470,9 @@ def test_bf16_halo_forward_and_dgrad(eng, N, Cin, Cout, H, W, two_src):
     else:
         node = _mk_node(eng, z, "relu", scale, shift)
         srcs = [node.src()]
-    assert eng._bf16_launch(srcs, wp, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, eng.EPI_PLAIN, eng.MORDER_LINEAR) == "halo"
+    c = eng.igemm_query(srcs, wp.Kpad, wp.Npad, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, ld0=Cout, precision="bf16",
+                        dst_dtype=eng._st(out))
+    assert c is not None and c.bf16 and ("halo" in c.name or "p8" in c.name or "c64p" in c.name)
     eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
     got = nchw(out.cpu())
     assert rel_err(got, ref) < 5e-4
@@ -499,7 +501,8 @@ def test_bf16_rejected_for_generic_shapes(eng):
     w = eng.pack_weight(rnd(g, 32, 32, 3, 3).cuda(), 9, 32, 32, 1, 32 * 9, 9)
     out = torch.empty((1, 16, 16, 32), device="cuda")
     srcs = [eng.plain_src(x0, 16), eng.plain_src(x1, 16)]
-    assert eng._bf16_launch(srcs, w, 1, 16, 16, 16, 16, 3, 3, 1, 1, eng.MODE_CONV, eng.EPI_PLAIN, eng.MORDER_LINEAR) is None
+    assert eng.igemm_query(srcs, w.Kpad, w.Npad, 1, 16, 16, 16, 16, 3, 3, 1, 1, eng.MODE_CONV, 32, ld0=32,
+                           precision="bf16") is None
     p = _lib.MsegIgemm()
     p.src[0], p.src[1] = srcs
     p.nsrc, p.Cin, p.Kpad, p.Npad, p.w = 2, 32, w.Kpad, w.Npad, w.bf16().data_ptr()
@@ -522,8 +525,9 @@ def test_bf16_gather_stride2_forward_and_dgrad(eng, N, Cin, Cout, H, W):
     Ho, Wo = ref.shape[2], ref.shape[3]
     node = _mk_node(eng, z, "relu", scale, shift)
     wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
-    assert eng._bf16_launch([node.src()], wp, N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, eng.EPI_PLAIN,
-                            eng.MORDER_LINEAR) == "fast"
+    c = eng.igemm_query([node.src()], wp.Kpad, wp.Npad, N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, Cout, ld0=Cout,
+                        precision="bf16")
+    assert c is not None and c.bf16 and c.name.startswith("igemm_fast_bf16_kernel")
     out = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
     eng.igemm([node.src()], wp, b.cuda(), N, H, W, Ho, Wo, 3, 3, 2, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
     assert rel_err(nchw(out.cpu()), ref) < 5e-4
@@ -536,9 +540,9 @@ def test_bf16_gather_stride2_forward_and_dgrad(eng, N, Cin, Cout, H, W):
     eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, Ho, Wo, H, W, 3, 3, 2, 1, eng.MODE_TCONV, Cin, dx, Cin,
               morder=eng.MORDER_PARITY, precision="bf16")
     # parity classes that are no whole 128-row tiles need the general kernel: the engine keeps that launch in fp32
-    kind = eng._bf16_launch([eng.plain_src(dz, Cout)], wd, N, Ho, Wo, H, W, 3, 3, 2, 1, eng.MODE_TCONV, eng.EPI_PLAIN,
-                            eng.MORDER_PARITY)
-    assert kind == ("fast" if (N * H * W) % 512 == 0 else None)
+    kind = eng.igemm_query([eng.plain_src(dz, Cout)], wd.Kpad, wd.Npad, N, Ho, Wo, H, W, 3, 3, 2, 1, eng.MODE_TCONV, Cin,
+                           ld0=Cin, morder=eng.MORDER_PARITY, precision="bf16", bias=False)
+    assert (kind is not None) == ((N * H * W) % 512 == 0)
     if kind is None:
         refd = F.conv_transpose2d(gy, w, None, stride=2, padding=1, output_padding=1)
     assert rel_err(nchw(dx.cpu()), refd) < 1e-4
@@ -594,7 +598,7 @@ def test_bf16_halo_wgrad(eng, N, Cin, Cout, H, W, two_src, act):
         qs = [keep.src()]
     dz = nhwc(gy).cuda()
     P = eng.plain_src(dz, Cout)
-    assert eng._wgrad_bf16_ok(P, qs, N, H, W, H, W, 3, 3, 1, 1)
+    assert eng.wgrad_query(P, qs, N, H, W, H, W, 3, 3, 1, 1, precision="bf16") is not None
     dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
     ws = eng.Workspace(torch.device("cuda"))
     eng.wgrad(P, qs, dW, N, H, W, H, W, 3, 3, 1, 1, ws, precision="bf16")
@@ -618,7 +622,7 @@ def test_bf16_strided_wgrads(eng, N, Cin, Cout, H, W):
     ref = torch.nn.grad.conv2d_weight(_bf(xin), (Cout, Cin, 3, 3), _bf(gy), stride=2, padding=1)
     dz = nhwc(gy).cuda()
     P = eng.plain_src(dz, Cout)
-    assert eng._wgrad_bf16_ok(P, [node.src()], N, Ho, Wo, H, W, 3, 3, 2, 1)
+    assert eng.wgrad_query(P, [node.src()], N, Ho, Wo, H, W, 3, 3, 2, 1, precision="bf16") is not None
     dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
     eng.wgrad(P, [node.src()], dW, N, Ho, Wo, H, W, 3, 3, 2, 1, ws, precision="bf16")
     assert rel_err(dW.cpu(), ref) < 5e-4
@@ -628,7 +632,7 @@ def test_bf16_strided_wgrads(eng, N, Cin, Cout, H, W):
     refT = torch.nn.grad.conv2d_weight(_bf(gy2), (Cin, Cout, 2, 2), _bf(xin), stride=2)
     dz2 = nhwc(gy2).cuda()
     Q = eng.plain_src(dz2, Cout)
-    assert eng._wgrad_bf16_ok(node.src(), [Q], N, H, W, 2 * H, 2 * W, 2, 2, 2, 0)
+    assert eng.wgrad_query(node.src(), [Q], N, H, W, 2 * H, 2 * W, 2, 2, 2, 0, precision="bf16") is not None
     dWT = torch.full((Cin, Cout, 2, 2), float("nan"), device="cuda")
     eng.wgrad(node.src(), [Q], dWT, N, H, W, 2 * H, 2 * W, 2, 2, 2, 0, ws, precision="bf16")
     assert rel_err(dWT.cpu(), refT) < 5e-4
@@ -982,6 +986,137 @@ def test_bf16_storage_256_pixel_tiles(eng, N, Cin, Cout, H, W, act, per_sample, 
             lib.mseg_igemm_set_wide_tiles(1)
     assert rel_err(got[0], refn + base.float()) < 6e-3
     assert rel_err(got[0], got[1]) < 8e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act,per_sample,two_src,want", [
+    (32, 128, 128, 96, 96, "relu", False, False, "igemm_p8_kernel<512, 128, 1>"),    # 32-wide tiles, 512 x 128
+    (20, 256, 256, 80, 80, "relu", True, True, "igemm_p8_kernel<256, 256, 1>"),       # 16-wide tiles, per-sample tables, concat
+    (32, 128, 256, 72, 64, "mish", False, False, "igemm_p8_kernel<256, 256, 2>"),     # tile rows below the image (72 = 9 x 8)
+    (40, 64, 128, 48, 48, "none", False, False, "igemm_p8_kernel<256, 128, 0>"),      # plain operand, 256 x 128 tiles
+    (36, 512, 1024, 32, 32, "elu", False, False, "igemm_p8_kernel<256, 256, 2>")])    # four 256-channel tiles per pixel tile
+def test_bf16_storage_p8_kernel(eng, N, Cin, Cout, H, W, act, per_sample, two_src, want):
+    """Layers with >= 128 output channels on bf16 tensors and at least one tile per CU take the one-workgroup-per-CU kernel
+    with DMA-streamed weights (igemm_p8.hip): persistent tile walk (more tiles than CUs, a ragged last round), transposed
+    accumulators with 16-byte stores, tables through LDS.  Forward with norm-on-load sources against torch on the rounded
+    operands and against the tile-per-workgroup kernels (mseg_igemm_set_p8(0)); data gradient into TWO accumulating bf16
+    destinations (the concat split) and into an fp32 destination; the library reports the kernel it took."""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3100 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    affine = act != "none"
+    nsc = (N, Cin) if per_sample else (Cin,)
+    scale = rnd(g, *nsc) * 0.3 + 1.0 if affine else None
+    shift = rnd(g, *nsc) * 0.1 if affine else None
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout)
+    ref = F.conv2d(_bf(_transform_cpu(z16.float(), act, scale, shift, per_sample)), _bf(w), b, padding=1)
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    sl = (lambda t, a, b_: t[:, a:b_]) if per_sample else (lambda t, a, b_: t[a:b_])
+    cuts = ((0, Cin // 2), (Cin // 2, Cin)) if two_src else ((0, Cin),)
+    nodes = []
+    for a, b_ in cuts:
+        n = _mk_node(eng, z16[:, a:b_].float(), act, sl(scale, a, b_).contiguous() if affine else None,
+                     sl(shift, a, b_).contiguous() if affine else None, per_sample)
+        n.z = n.z.to(torch.bfloat16)
+        nodes.append(n)
+    srcs = [n.src() for n in nodes]
+    outs = []
+    for mode in (1, 0):
+        assert lib.mseg_igemm_set_p8(mode) == 0
+        try:
+            out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16")
+            torch.cuda.synchronize()
+            if mode == 1:
+                assert lib.mseg_last_kernel().decode() == want
+            else:
+                assert "p8" not in lib.mseg_last_kernel().decode()
+            outs.append(out.float().cpu())
+        finally:
+            lib.mseg_igemm_set_p8(1)
+    assert rel_err(nchw(outs[0]), ref) < (6e-3 if act in ("relu", "none") else 8e-3)
+    assert rel_err(outs[0], outs[1]) < 8e-3              # same operands, another fp32 accumulation order: at most one bf16 ulp
+    # data gradient (plain operand dz; N = Cin >= 128 only): two accumulating bf16 destinations split at Cin / 2
+    if Cin < 128:
+        return
+    gy16 = _b16(rnd(g, N, Cout, H, W))
+    refn = nhwc(F.conv_transpose2d(gy16.float(), _bf(w), None, padding=1))
+    wd = eng.pack_weight(w.cuda(), 9, Cin, Cout, 1, 9, Cin * 9)
+    dz = nhwc(gy16).cuda()
+    half = Cin // 2
+    base0, base1 = _b16(rnd(g, N, H, W, half)), _b16(rnd(g, N, H, W, Cin - half))
+    got = []
+    for mode in (1, 0):
+        assert lib.mseg_igemm_set_p8(mode) == 0
+        try:
+            d0, d1 = base0.clone().cuda(), base1.clone().cuda()
+            eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d0, half, acc0=1,
+                      dst1=d1, ld1=Cin - half, acc1=1, split=half, precision="bf16")
+            torch.cuda.synchronize()
+            if mode == 1:
+                assert lib.mseg_last_kernel().decode().startswith("igemm_p8_kernel")
+            got.append(torch.cat([d0.float().cpu(), d1.float().cpu()], dim=3))
+        finally:
+            lib.mseg_igemm_set_p8(1)
+    want_d = refn + torch.cat([base0.float(), base1.float()], dim=3)
+    assert rel_err(got[0], want_d) < 6e-3
+    assert rel_err(got[0], got[1]) < 8e-3
+    # fp32 destination, no accumulation
+    d32 = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    eng.igemm([eng.plain_src(dz, Cout)], wd, None, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_TCONV, Cin, d32, Cin, precision="bf16")
+    assert lib.mseg_last_kernel().decode().startswith("igemm_p8_kernel")
+    assert rel_err(d32.cpu(), refn) < 1e-4
+
+
+def test_dispatch_query_equals_launch(eng):
+    """mseg_igemm_query / mseg_wgrad_query run the dispatch code itself with the launches switched off: for a sweep of layer
+    shapes (both precisions, tensor storages, strides, concat, ConvTranspose forms) the kernel a query names is the kernel
+    the launch then takes (mseg_last_kernel)."""
+    from microbeseg_amd import _lib
+    from microbeseg_amd._lib import ST_F32, ST_BF16, ACT
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    n_checked = 0
+    for prec, st in (("fp32", torch.float32), ("bf16", torch.float32), ("bf16", torch.bfloat16)):
+        for (N, cins, cout, H, W, stride) in [(2, (8,), 16, 16, 16, 1), (4, (64,), 64, 64, 64, 1), (32, (128,), 128, 96, 96, 1),
+                                              (16, (128, 128), 256, 40, 40, 1), (3, (16,), 8, 20, 12, 1),
+                                              (8, (64,), 64, 64, 64, 2), (2, (136,), 72, 10, 14, 1), (32, (64,), 64, 160, 160, 1)]:
+            cin = sum(cins)
+            if st == torch.bfloat16 and (cin % 8 or cout % 8 or any(c % 8 for c in cins)):
+                continue
+            Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+            nodes = []
+            for c in cins:
+                n = _mk_node(eng, rnd(g, N, c, H, W), "relu", rnd(g, c) * 0.1 + 1, rnd(g, c) * 0.1)
+                n.z = n.z.to(st)
+                nodes.append(n)
+            srcs = [n.src() for n in nodes]
+            w = rnd(g, cout, cin, 3, 3) * 0.05
+            wp = eng.pack_weight(w.cuda(), 9, cout, cin, 1, cin * 9, 9)
+            out = torch.empty((N, Ho, Wo, cout), device="cuda", dtype=st)
+            q = eng.igemm_query(srcs, wp.Kpad, wp.Npad, N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, cout, ld0=cout,
+                                precision=prec, dst_dtype=eng._st(out), bias=False)
+            if q is None:                                # no bf16 kernel: the engine keeps the launch in fp32
+                assert prec == "bf16"
+                if st == torch.bfloat16:
+                    continue
+                q = eng.igemm_query(srcs, wp.Kpad, wp.Npad, N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, cout, ld0=cout,
+                                    precision="fp32", dst_dtype=eng._st(out), bias=False)
+            eng.igemm(srcs, wp, None, N, H, W, Ho, Wo, 3, 3, stride, 1, eng.MODE_CONV, cout, out, cout, precision=prec)
+            assert lib.mseg_last_kernel().decode() == q.name, (prec, st, N, cins, cout, H, W, stride)
+            # weight gradient of the same layer
+            dz = torch.randn(N, Ho, Wo, cout, device="cuda").to(st)
+            P = eng.plain_src(dz, cout)
+            qw = eng.wgrad_query(P, srcs, N, Ho, Wo, H, W, 3, 3, stride, 1, precision=prec)
+            if qw is None:
+                if st == torch.bfloat16:
+                    continue
+                qw = eng.wgrad_query(P, srcs, N, Ho, Wo, H, W, 3, 3, stride, 1, precision="fp32")
+            dW = torch.empty((cout, cin, 3, 3), device="cuda")
+            eng.wgrad(P, srcs, dW, N, Ho, Wo, H, W, 3, 3, stride, 1, eng.Workspace(torch.device("cuda")), precision=prec)
+            assert lib.mseg_last_kernel().decode() == qw.name, ("wgrad", prec, st, N, cins, cout, H, W, stride)
+            n_checked += 1
+    assert n_checked >= 12
 
 
 @pytest.mark.parametrize("N,H,W,act,per_sample,dst32", [(8, 128, 128, "relu", False, False), (16, 96, 96, "mish", True, False),

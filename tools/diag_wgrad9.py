@@ -16,7 +16,7 @@ def run(N, Cin, Cout, H, W):
     dz = gy.permute(0, 2, 3, 1).contiguous().cuda()
     P = eng.plain_src(dz, Cout)
     dW = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
-    name = eng._wgrad_kernel_name(P, [q], N, H, W, H, W, 3, 1)
+    name = eng.wgrad_query(P, [q], N, H, W, H, W, 3, 3, 1, 1).name
     eng.wgrad(P, [q], dW, N, H, W, H, W, 3, 3, 1, 1, eng.Workspace(torch.device("cuda")))
     torch.cuda.synchronize()
     d = dW.cpu()
