@@ -159,6 +159,22 @@ int mseg_wgrad_query(const MsegWgrad* p, MsegKernelInfo* info);
 /* z_dtype / dz_dtype: MSEG_ST_F32 or MSEG_ST_BF16 — how z is stored / dz is read (the network input x4 is always fp32) */
 int mseg_first_conv_fwd(const float* x4, const float* w, const float* bias, int N, int H, int W, int Cin, int Cout,
                         void* z, int z_dtype, void* stream);
+/* K14 on the device — the frame normalisation of the inference loop (reference: infer.py:346-348,
+ * infer_script_local.py:130-132: min / max of the frame, top / left padding with min (utils.py:124-163),
+ * 2 * (f32(x) - min) / (max - min) - 1) without the host touching a pixel:
+ *   mseg_frame_minmax        raw: [npix] uint8 (MSEG_PIX_U8) / uint16 (MSEG_PIX_U16) -> minmax[2] on the device ({~min, max})
+ *   mseg_first_conv_fwd_raw  the first convolution Conv2d(1, Cout, 3, padding=1) of ONE frame, reading the raw frame and
+ *                            normalising / padding while it loads: the same fp32 operations in the same order as the host
+ *                            formula (bit-identical input values); z: [H0 + pad_top][W0 + pad_left][Cout]
+ *   mseg_frame_normalize     the normalised, padded frame itself (fp32 [H0 + pad_top][W0 + pad_left]) for networks whose
+ *                            first layer does not take the kernel above                                                   */
+#define MSEG_PIX_U8 0
+#define MSEG_PIX_U16 1
+int mseg_frame_minmax(const void* raw, int dtype, size_t npix, uint32_t* minmax, void* stream);
+int mseg_first_conv_fwd_raw(const void* raw, int dtype, int H0, int W0, int pad_top, int pad_left, const uint32_t* minmax,
+                            const float* w, const float* bias, int Cout, void* z, int z_dtype, void* stream);
+int mseg_frame_normalize(const void* raw, int dtype, int H0, int W0, int pad_top, int pad_left, const uint32_t* minmax,
+                         float* out, void* stream);
 size_t mseg_first_wgrad_workspace_bytes(int N, int H, int W, int Cout);
 int mseg_first_wgrad(const float* x4, const void* dz, int dz_dtype, int N, int H, int W, int Cout, float* dW, void* ws,
                      void* stream);
@@ -189,8 +205,12 @@ int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned tot
  *   y = a*scale + shift, and mean/rstd ([C] BN, [N][8] GN, [N][C] IN) for the backward.
  *   BN training additionally updates running_mean/var with `momentum` (unbiased var), torch semantics
  *   (unets.py:127-128; torch BatchNorm2d defaults eps 1e-5, momentum 0.1).
- * ws: fp64 scratch, mseg_norm_workspace_bytes(N, HW, C).                                                      */
+ * ws: scratch of mseg_norm_workspace_bytes(N, HW, C) bytes.  Its first 64 KiB hold the arrival counters of the in-kernel
+ * reductions (the last workgroups of a pass finish the sums and write the tables: no separate reduction launches):
+ * ZERO them once after allocating ws (hipMemset); every call leaves them zero.  One ws per concurrent stream.          */
 size_t mseg_norm_workspace_bytes(int N, int HW, int C);
+/* Test / ablation hook: 0 = a pass is followed by separate reduction / finalize launches again (same results). Default 1. */
+int mseg_norm_set_tails(int on);
 /* st: MSEG_ST_F32 / MSEG_ST_BF16 = storage of the activation tensors of the call (z, act_out; gy, dz, act_in below).  With
  * bf16 storage a thread owns 8 channels (C % 8 == 0) and the statistics are those of the values as stored.           */
 int mseg_norm_stats(const void* z, int N, int HW, int C, int st, int act, int norm, const float* gamma,

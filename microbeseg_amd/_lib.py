@@ -82,6 +82,9 @@ SIGNATURES = {
     "mseg_igemm_set_p8": (_I, [_I]),
     "mseg_f32_to_bf16": (_I, [_P, _P, _SZ, _P]),
     "mseg_first_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "mseg_frame_minmax": (_I, [_P, _I, _SZ, _P, _P]),
+    "mseg_first_conv_fwd_raw": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "mseg_frame_normalize": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_first_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "mseg_first_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_wgrad_workspace_bytes": (_SZ, [C.POINTER(MsegWgrad)]),
@@ -91,6 +94,7 @@ SIGNATURES = {
     "mseg_pack_job_blocks": (C.c_uint, [_I, _I, _I]),
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "mseg_norm_set_tails": (_I, [_I]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mseg_activation": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),

@@ -66,10 +66,69 @@ __global__ __launch_bounds__(256) void first_conv_fwd_kernel(const float* __rest
 // Same accumulation order as above (bias, then taps row-major; a tap outside the image adds 0).
 #define FR_ROWS 8
 
-template <bool S16>
+// ---- K14: frame normalisation on the device (reference: infer.py:346-348, infer_script_local.py:130-132) --------------------
+// The reference normalises a frame on the host, `2 * (img.astype(np.float32) - min) / (max - min) - 1` with min / max the
+// frame's extrema as scalars of the image dtype, after padding its top / left edge with `min` (utils.py:124-163) — i.e. pad
+// pixels become exactly -1.  Here the raw uint8 / uint16 frame is uploaded as it is, `frame_minmax_kernel` reduces the
+// extrema on the device (integer atomics: order-independent) and the first convolution applies the same fp32 operations
+// in the same order while it loads its 3 x 3 window (explicit round-to-nearest operations: no fused multiply-add), so the
+// host never touches a pixel and no normalised or padded copy of the frame exists.
+struct RawFrame {
+  const void* raw;               // [H0][W0] uint8 / uint16
+  const uint32_t* minmax;        // device: {~min, max} as written by frame_minmax_kernel
+  int dtype, H0, W0, pad_top, pad_left;
+};
+
+__device__ __forceinline__ float raw_frame_norm(unsigned v, float fmin, float frange) {
+  // 2 * (f32(x) - min) / (max - min) - 1 as numpy evaluates it on a float32 array with integer scalars
+  return __fsub_rn(__fdiv_rn(__fmul_rn(2.f, __fsub_rn((float)v, fmin)), frange), 1.f);
+}
+__device__ __forceinline__ float raw_frame_px(const RawFrame& f, int yy, int xx, int H, int W, float fmin, float frange) {
+  if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return 0.f;     // the convolution's zero padding
+  const int y0 = yy - f.pad_top, x0 = xx - f.pad_left;
+  if (y0 < 0 || x0 < 0) return -1.f;                                              // frame padding (value `min`)
+  const size_t i = (size_t)y0 * f.W0 + x0;
+  const unsigned v = f.dtype == MSEG_PIX_U8 ? reinterpret_cast<const uint8_t*>(f.raw)[i]
+                                            : reinterpret_cast<const uint16_t*>(f.raw)[i];
+  return raw_frame_norm(v, fmin, frange);
+}
+
+__global__ __launch_bounds__(256) void frame_minmax_kernel(const void* __restrict__ raw, int dtype, size_t n,
+                                                           uint32_t* __restrict__ minmax) {
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned v = dtype == MSEG_PIX_U8 ? reinterpret_cast<const uint8_t*>(raw)[i]
+                                            : reinterpret_cast<const uint16_t*>(raw)[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {                       // both words start at 0: the minimum is kept inverted
+    atomicMax(minmax, ~lo);
+    atomicMax(minmax + 1, hi);
+  }
+}
+
+// the normalised, padded frame as an fp32 tensor [H][W] (networks whose first layer does not take the fused kernel below)
+__global__ __launch_bounds__(256) void frame_normalize_kernel(const RawFrame f, int H, int W, float* __restrict__ out) {
+  const float fmin = (float)(~f.minmax[0]), frange = (float)(f.minmax[1] - ~f.minmax[0]);
+  const size_t n = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int yy = (int)(i / W), xx = (int)(i - (size_t)yy * W);
+    out[i] = raw_frame_px(f, yy, xx, H, W, fmin, frange);
+  }
+}
+
+// RAW: the input is a raw frame (RawFrame, one image, H x W = its padded size) instead of the 4-channel fp32 tensor
+template <bool S16, bool RAW>
 __global__ __launch_bounds__(256) void first_conv_fwd_rows_kernel(const float* __restrict__ x4, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, int H, int W, int Cout,
-                                                                  void* __restrict__ z) {
+                                                                  void* __restrict__ z, const RawFrame rf) {
   const int CG = Cout >> 3;                  // channel groups of 8
   const int XS = 256 / CG;                   // image columns per workgroup
   const int cg = threadIdx.x % CG, xs = threadIdx.x / CG;
@@ -84,8 +143,11 @@ __global__ __launch_bounds__(256) void first_conv_fwd_rows_kernel(const float* _
   for (int j = 0; j < 8; ++j) b[j] = bias ? bias[co + j] : 0.f;
   const int x = blockIdx.x * XS + xs, y0 = blockIdx.y * FR_ROWS, n = blockIdx.z;
   if (x >= W) return;
-  const float* const img = x4 + (size_t)n * H * W * 4;
+  const float* const img = RAW ? nullptr : x4 + (size_t)n * H * W * 4;
+  float fmin = 0.f, frange = 1.f;
+  if (RAW) { fmin = (float)(~rf.minmax[0]); frange = (float)(rf.minmax[1] - ~rf.minmax[0]); }
   auto px = [&](int yy, int xx) -> float {
+    if (RAW) return raw_frame_px(rf, yy, xx, H, W, fmin, frange);
     return ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[((size_t)yy * W + xx) * 4] : 0.f;
   };
   float win[3][3];                           // rows y - 1, y, y + 1; columns x - 1, x, x + 1
@@ -290,10 +352,11 @@ extern "C" int mseg_first_conv_fwd(const float* x4, const float* w, const float*
   if (first_rows_ok(Cin, Cout) && (H + FR_ROWS - 1) / FR_ROWS <= 65535 && N <= 65535) {
     const int XS = 256 / (Cout >> 3);
     const dim3 grid((unsigned)((W + XS - 1) / XS), (unsigned)((H + FR_ROWS - 1) / FR_ROWS), (unsigned)N);
+    const RawFrame none = {};
     if (z_dtype == MSEG_ST_BF16)
-      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z);
+      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z, none);
     else
-      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z);
+      hipLaunchKernelGGL((first_conv_fwd_rows_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, x4, w, bias, H, W, Cout, z, none);
     MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }
@@ -306,6 +369,56 @@ extern "C" int mseg_first_conv_fwd(const float* x4, const float* w, const float*
   else
     hipLaunchKernelGGL((first_conv_fwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x4, w, bias,
                        N, H, W, Cin, Cout, z, z_dtype);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+static int raw_frame_check(const void* raw, int dtype, int H0, int W0, int pad_top, int pad_left, const uint32_t* minmax) {
+  if (!raw || !minmax || (dtype != MSEG_PIX_U8 && dtype != MSEG_PIX_U16) || H0 <= 0 || W0 <= 0 || pad_top < 0 || pad_left < 0)
+    return MSEG_EINVAL;
+  if ((long long)H0 + pad_top > 65535 * (long long)FR_ROWS || (long long)W0 + pad_left > 0x7fffffffLL) return MSEG_EINVAL;
+  return MSEG_OK;
+}
+
+extern "C" int mseg_frame_minmax(const void* raw, int dtype, size_t npix, uint32_t* minmax, void* stream) {
+  if (!raw || !minmax || npix == 0 || (dtype != MSEG_PIX_U8 && dtype != MSEG_PIX_U16)) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(minmax, 0, 2 * sizeof(uint32_t), st) != hipSuccess) return MSEG_ELAUNCH;
+  size_t blocks = (npix + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(frame_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, dtype, npix, minmax);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_frame_normalize(const void* raw, int dtype, int H0, int W0, int pad_top, int pad_left,
+                                    const uint32_t* minmax, float* out, void* stream) {
+  if (raw_frame_check(raw, dtype, H0, W0, pad_top, pad_left, minmax) || !out) return MSEG_EINVAL;
+  const RawFrame f = {raw, minmax, dtype, H0, W0, pad_top, pad_left};
+  const int H = H0 + pad_top, W = W0 + pad_left;
+  size_t blocks = ((size_t)H * W + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(frame_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, H, W, out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_first_conv_fwd_raw(const void* raw, int dtype, int H0, int W0, int pad_top, int pad_left,
+                                       const uint32_t* minmax, const float* w, const float* bias, int Cout, void* z,
+                                       int z_dtype, void* stream) {
+  if (raw_frame_check(raw, dtype, H0, W0, pad_top, pad_left, minmax) || !w || !z) return MSEG_EINVAL;
+  if (z_dtype != MSEG_ST_F32 && z_dtype != MSEG_ST_BF16) return MSEG_EINVAL;
+  const int H = H0 + pad_top, W = W0 + pad_left;
+  if (!first_shape_ok(1, H, W, 1, Cout) || !first_rows_ok(1, Cout)) return MSEG_EINVAL;
+  const RawFrame f = {raw, minmax, dtype, H0, W0, pad_top, pad_left};
+  const int XS = 256 / (Cout >> 3);
+  const dim3 grid((unsigned)((W + XS - 1) / XS), (unsigned)((H + FR_ROWS - 1) / FR_ROWS), 1u);
+  if (z_dtype == MSEG_ST_BF16)
+    hipLaunchKernelGGL((first_conv_fwd_rows_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, w,
+                       bias, H, W, Cout, z, f);
+  else
+    hipLaunchKernelGGL((first_conv_fwd_rows_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, w,
+                       bias, H, W, Cout, z, f);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

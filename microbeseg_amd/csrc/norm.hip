@@ -8,22 +8,30 @@
 // channel reduction needs no shuffles across lanes; partial sums meet in LDS (fp64) and then in a fixed-order
 // second stage (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 struct NormGeom {
   int N, HW, C, chunks, rows_per_chunk;
+  int cw, slices;       // channel groups (of V channels) per workgroup, channel slices of a tensor row
 };
+
+#define NORM_CTR_BYTES 65536          // head of the workspace: arrival counters of the in-kernel tails (see norm_tail_*)
+#define NORM_CTR_MAX (NORM_CTR_BYTES / 4)
 
 static NormGeom norm_geom(int N, int HW, int C, int vec = 4) {
   NormGeom g;
   g.N = N; g.HW = HW; g.C = C;
-  // one workgroup per (chunk of rows, sample); aim at >= 4096 workgroups (16 per CU) with at least 16 rows per row slot
-  // of a workgroup (256 threads = rpi rows x C/vec channel groups), so that deep levels (few pixels, many channels) still
-  // fill the chip and level 0 keeps long streaming loops
+  // A workgroup = 256 threads = rpi row slots x cw channel groups (a thread owns V channels of its rows), one per
+  // (chunk of rows, sample, slice of <= 16 channel groups).  Slicing the channels keeps >= 16 row slots per workgroup at
+  // any channel count and gives the reductions over chunks / samples of a slice to the LAST workgroup of that slice (the
+  // in-kernel tails below) in small pieces.  Aim at 2048 workgroups (eight per CU: all resident at once, each a long streaming loop — and half the
+  // partial sums of the 4096 of earlier rounds for the tails to read) with at least 8 rows per row slot.
   const int C4 = C / vec;
-  const int CW = C4 < 256 ? (C4 > 0 ? C4 : 1) : 256;
-  const int rpi = 256 / CW;
-  const int min_rows = 16 * rpi;
-  int want = (4096 + N - 1) / (N > 0 ? N : 1);
+  g.cw = C4 < 16 ? (C4 > 0 ? C4 : 1) : 16;
+  g.slices = (C4 + g.cw - 1) / g.cw;
+  const int rpi = 256 / g.cw;
+  const int min_rows = 8 * rpi;
+  int want = (2048 + N * g.slices - 1) / (N * g.slices > 0 ? N * g.slices : 1);
   int chunks = HW / min_rows;
   if (chunks > want) chunks = want;
   if (chunks < 1) chunks = 1;
@@ -37,9 +45,10 @@ static inline int norm_vec(int st) { return st == MSEG_ST_BF16 ? 8 : 4; }
 
 extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0) return 0;
-  NormGeom g = norm_geom(N, HW, C);          // the fp32 geometry has the larger chunk count
-  // fp64 partials [N][chunks][3][C] + per-(n,c) sums [3][N][C] + fp32 k-tables [3][N][C] (2*N*C doubles)
-  return ((size_t)N * g.chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
+  NormGeom g4 = norm_geom(N, HW, C, 4), g8 = norm_geom(N, HW, C, 8);
+  const int chunks = g4.chunks > g8.chunks ? g4.chunks : g8.chunks;
+  // arrival counters + fp64 partials [N][chunks][3][C] + per-(n,c) sums [3][N][C] + fp32 k-tables [3][N][C] (2*N*C doubles)
+  return NORM_CTR_BYTES + ((size_t)N * chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
 }
 
 // V consecutive channels (V = 4: fp32 storage, V = 8: bf16 storage) at element offset e.  Loaded values stay in their 16 raw
@@ -86,6 +95,63 @@ struct NormVec {
   }
 };
 
+// ---- in-kernel tails: what used to be three more launches per pass ---------------------------------------------------------
+// A pass leaves fp64 partial sums per (sample, chunk of rows, channel).  Reducing them over the chunks, then over the
+// samples (BatchNorm, bias gradients) or over the channels of a group (Group / InstanceNorm), and turning the sums into
+// the tables the next kernels read took `norm_reduce_chunks` + a finalize kernel (+ `norm_colsum`) per pass: six ~5 us
+// launches per layer and step, each with its dispatch gap.  Now the LAST workgroup to arrive does it:
+//   level 1: the workgroups of one (sample, channel slice) count their arrivals; the last one sums that slice's chunks in
+//            a fixed order and publishes nc[s][n][c];
+//   level 2: those level-1 finishers count arrivals per channel slice (BatchNorm / column sums: N arrivals) or per sample
+//            (per-sample norms: `slices` arrivals); the last one finishes its slice / sample and writes the tables.
+// Every summation order is fixed by the indices, never by arrival order: results are bit-reproducible.
+// Hand-off (cdna_hip_programming.md, Guideline 16): payload by write-through (sc1) stores, every storing wave drains its
+// stores, workgroup barrier, ONE lane's relaxed agent-scope add; the finisher runs ONE agent-scope acquire and then reads
+// the payload with plain loads (several in flight).  No release fence: a pass that has just written a tensor must not flush its L2.
+// Counters: NORM_CTR_BYTES at the head of the workspace, zero before the first call, left zero by every call.
+typedef __attribute__((address_space(1))) unsigned long long norm_gu64;
+typedef __attribute__((address_space(1))) unsigned norm_gu32;
+__device__ __forceinline__ void norm_st_sc1(double* p, double v) {
+  __hip_atomic_store((norm_gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double norm_ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((norm_gu64*)const_cast<double*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+// true (in every thread) in the workgroup whose arrival completes `expected`; that workgroup leaves the counter zero
+__device__ __forceinline__ bool norm_arrive(unsigned* ctr, unsigned expected, int tid, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its write-through stores have left
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add((norm_gu32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == expected - 1u;
+    if (last) {
+      __hip_atomic_store((norm_gu32*)ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *s_flag = last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+#define NORM_TAIL_NONE 0
+#define NORM_TAIL_BN_FWD 1     // statistics -> scale / shift / mean / rstd / running statistics
+#define NORM_TAIL_PS_FWD 2     // the same per sample (GroupNorm, InstanceNorm)
+#define NORM_TAIL_BN_BWD 3     // sums of (gy, gy a) -> k1, k2, k3, dgamma, dbeta
+#define NORM_TAIL_COLSUM 4     // sum of dz over samples -> the producing convolution's bias gradient
+struct NormTail {
+  int kind, norm;
+  unsigned* ctr;               // NORM_CTR_MAX counters
+  double* nc;                  // [3][N][C] per-(sample, channel) sums
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float *scale, *shift, *mean_out, *rstd_out, *running_mean, *running_var;   // forward
+  const float *mean, *rstd;                                                   // backward
+  float *k1, *k2, *k3, *dgamma, *dbeta, *colsum;
+};
+
 // MODE 0: forward  sums of (a, a*a)           from z        (+ optional store of a = act(z) into `aio`)
 // MODE 1: backward sums of (gy, gy*a)         from (gy, z)  (a read from `aio` when given)
 // MODE 2: backward apply: dz = (k1*gy + k2*a + k3) * act'(z), sums of (dz)  (a recomputed from z, never read)
@@ -94,18 +160,20 @@ struct NormVec {
 // conv / wgrad K-loops do not re-evaluate transcendentals for each of the 9 taps and every output tile.
 // S16: z, gy, dz and aio are bf16 tensors (the sums are taken over the values as stored, i.e. of the rounded dz).
 // AIO: the launch carries `aio` (compile-time, so that the ReLU / no-activation passes keep their exact code)
+// grid: (chunks, N, slices)
 template <int MODE, bool S16, bool AIO>
 __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__ z, const void* __restrict__ gy,
                                                         void* __restrict__ dz, const float* __restrict__ k1,
                                                         const float* __restrict__ k2, const float* __restrict__ k3,
                                                         int kss, NormGeom g, int act, double* __restrict__ part,
-                                                        void* __restrict__ aio) {
+                                                        void* __restrict__ aio, const NormTail t) {
   constexpr int V = S16 ? 8 : 4;
   __shared__ double red[256 * 2 * V];
+  __shared__ int s_flag;
   const int tid = threadIdx.x;
-  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int chunk = blockIdx.x, n = blockIdx.y, slice = blockIdx.z;
   const int C4 = g.C / V;
-  const int CW = C4 < 256 ? C4 : 256;
+  const int CW = g.cw;
   const int rpi = 256 / CW;
   const int cq = tid % CW, r0 = tid / CW;
   const int row_begin = chunk * g.rows_per_chunk;
@@ -113,119 +181,236 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
   if (row_end > g.HW) row_end = g.HW;
   constexpr int NS = (MODE == 2) ? 1 : 2;
   double* pout = part + ((size_t)n * g.chunks + chunk) * 3 * g.C;
-
-  for (int cbase = 0; cbase < C4; cbase += CW) {
-    const int c4 = cbase + cq;
-    const bool active = (c4 < C4) && (r0 < rpi);
-    double s0[V], s1[V];
+  const int c4 = slice * CW + cq;
+  const bool active = (c4 < C4) && (r0 < rpi);
+  double s0[V], s1[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
-    if (active) {
-      const int c = c4 * V;
-      float a1[V], a2[V], a3[V];
-      if (MODE == 2) {
+  for (int j = 0; j < V; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+  if (active) {
+    const int c = c4 * V;
+    float a1[V], a2[V], a3[V];
+    if (MODE == 2) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          a1[j] = k1[(size_t)n * kss + c + j]; a2[j] = k2[(size_t)n * kss + c + j]; a3[j] = k3[(size_t)n * kss + c + j];
-        }
+      for (int j = 0; j < V; ++j) {
+        a1[j] = k1[(size_t)n * kss + c + j]; a2[j] = k2[(size_t)n * kss + c + j]; a3[j] = k3[(size_t)n * kss + c + j];
       }
-      // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
-      // one load pair per trip left the pass latency-bound at ~3 TB/s
-      constexpr int U = (MODE == 0 && !AIO) ? 8 : !S16 ? 4 : MODE == 1 ? (AIO ? 2 : 4) : MODE == 2 ? 2 : 4;   // measured per pass (registers vs loads in flight)
-      for (int r = row_begin + r0; r < row_end; r += rpi * U) {
-        NormVec<S16> zv[U], gv[U], av[U];
-        bool ok[U];
+    }
+    // U rows per trip, all loads issued before any use: a thread keeps U (x 2-3 operands) 16-byte loads in flight —
+    // one load pair per trip left the pass latency-bound at ~3 TB/s
+    constexpr int U = (MODE == 0 && !AIO) ? 8 : !S16 ? 4 : MODE == 1 ? (AIO ? 2 : 4) : MODE == 2 ? 2 : 4;   // measured per pass (registers vs loads in flight)
+    for (int r = row_begin + r0; r < row_end; r += rpi * U) {
+      NormVec<S16> zv[U], gv[U], av[U];
+      bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ru = r + u * rpi;
-          ok[u] = ru < row_end;
-          const size_t off = ((size_t)n * g.HW + (ok[u] ? ru : r)) * g.C + c;
-          if (MODE != 1 || !AIO) zv[u].load(z, off);            // the sums of MODE 1 need a only: z stays in HBM when a is stored
-          if (MODE == 1 && AIO) av[u].load(aio, off);           // MODE 2 recomputes a next to act'(z) instead (act_pair)
-          if (MODE == 1 || MODE == 2) gv[u].load(gy, off);
+      for (int u = 0; u < U; ++u) {
+        const int ru = r + u * rpi;
+        ok[u] = ru < row_end;
+        const size_t off = ((size_t)n * g.HW + (ok[u] ? ru : r)) * g.C + c;
+        if (MODE != 1 || !AIO) zv[u].load(z, off);            // the sums of MODE 1 need a only: z stays in HBM when a is stored
+        if (MODE == 1 && AIO) av[u].load(aio, off);           // MODE 2 recomputes a next to act'(z) instead (act_pair)
+        if (MODE == 1 || MODE == 2) gv[u].load(gy, off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
+        float zf[V], a4[V];
+        if (MODE != 1 || !AIO) zv[u].get(zf);
+        if (MODE == 2 && AIO) {                 // expensive activation: a (as the forward stored it) and act'(z) in one go
+          float gf[V], d[V];
+          gv[u].get(gf);
+#pragma unroll
+          for (int j = 0; j < V; ++j) act_pair<S16>(zf[j], act, a4[j], d[j]);
+          NormVec<S16>::round(a4);
+#pragma unroll
+          for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * d[j];
+          NormVec<S16>::put(dz, off, d);
+#pragma unroll
+          for (int j = 0; j < V; ++j) s0[j] += d[j];
+          continue;
         }
+        if (MODE == 1 && AIO) av[u].get(a4);
+        else {
+          if (S16 && act != MSEG_ACT_NONE && act != MSEG_ACT_RELU) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!ok[u]) continue;
-          const size_t off = ((size_t)n * g.HW + r + u * rpi) * g.C + c;
-          float zf[V], a4[V];
-          if (MODE != 1 || !AIO) zv[u].get(zf);
-          if (MODE == 2 && AIO) {                 // expensive activation: a (as the forward stored it) and act'(z) in one go
-            float gf[V], d[V];
-            gv[u].get(gf);
+            for (int j = 0; j < V; ++j) a4[j] = act_fwd_fast(zf[j], act);
+          } else {
 #pragma unroll
-            for (int j = 0; j < V; ++j) act_pair<S16>(zf[j], act, a4[j], d[j]);
-            NormVec<S16>::round(a4);
+            for (int j = 0; j < V; j += 4) {       // act_fwd4: the cheap activations take a wave-uniform fast path
+              const float4 t4 = act_fwd4(make_float4(zf[j], zf[j + 1], zf[j + 2], zf[j + 3]), act);
+              a4[j] = t4.x; a4[j + 1] = t4.y; a4[j + 2] = t4.z; a4[j + 3] = t4.w;
+            }
+          }
+        }
+        if ((MODE == 0 || MODE == 3) && AIO)
+          NormVec<S16>::put(aio, off, a4);      // the consumers read the ROUNDED activation: the statistics describe that
+        if (MODE == 3) continue;
+        if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * d[j];
-            NormVec<S16>::put(dz, off, d);
+          for (int j = 0; j < V; ++j) { s0[j] += a4[j]; s1[j] += (double)a4[j] * a4[j]; }
+        } else {
+          float gf[V];
+          gv[u].get(gf);
+          if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] += gf[j]; s1[j] += (double)gf[j] * a4[j]; }
+          } else {
+            float d[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+              d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * (S16 ? act_bwd_fast(zf[j], act) : act_bwd(zf[j], act));
+            NormVec<S16>::put(dz, off, d);      // d now holds dz as stored
 #pragma unroll
             for (int j = 0; j < V; ++j) s0[j] += d[j];
-            continue;
-          }
-          if (MODE == 1 && AIO) av[u].get(a4);
-          else {
-            if (S16 && act != MSEG_ACT_NONE && act != MSEG_ACT_RELU) {
-#pragma unroll
-              for (int j = 0; j < V; ++j) a4[j] = act_fwd_fast(zf[j], act);
-            } else {
-#pragma unroll
-              for (int j = 0; j < V; j += 4) {       // act_fwd4: the cheap activations take a wave-uniform fast path
-                const float4 t = act_fwd4(make_float4(zf[j], zf[j + 1], zf[j + 2], zf[j + 3]), act);
-                a4[j] = t.x; a4[j + 1] = t.y; a4[j + 2] = t.z; a4[j + 3] = t.w;
-              }
-            }
-          }
-          if ((MODE == 0 || MODE == 3) && AIO)
-            NormVec<S16>::put(aio, off, a4);      // the consumers read the ROUNDED activation: the statistics describe that
-          if (MODE == 3) continue;
-          if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < V; ++j) { s0[j] += a4[j]; s1[j] += (double)a4[j] * a4[j]; }
-          } else {
-            float gf[V];
-            gv[u].get(gf);
-            if (MODE == 1) {
-#pragma unroll
-              for (int j = 0; j < V; ++j) { s0[j] += gf[j]; s1[j] += (double)gf[j] * a4[j]; }
-            } else {
-              float d[V];
-#pragma unroll
-              for (int j = 0; j < V; ++j)
-                d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * (S16 ? act_bwd_fast(zf[j], act) : act_bwd(zf[j], act));
-              NormVec<S16>::put(dz, off, d);      // d now holds dz as stored
-#pragma unroll
-              for (int j = 0; j < V; ++j) s0[j] += d[j];
-            }
           }
         }
       }
     }
-    if (MODE == 3) continue;
+  }
+  if (MODE == 3) return;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      red[tid * 2 * V + j] = s0[j];
-      red[tid * 2 * V + V + j] = s1[j];
-    }
-    __syncthreads();
-    if (r0 == 0 && c4 < C4) {
-      double t0[V], t1[V];
+  for (int j = 0; j < V; ++j) {
+    red[tid * 2 * V + j] = s0[j];
+    red[tid * 2 * V + V + j] = s1[j];
+  }
+  __syncthreads();
+  if (r0 == 0 && c4 < C4) {
+    double t0[V], t1[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
-      for (int k = 0; k < rpi; ++k) {
+    for (int j = 0; j < V; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
+    for (int k = 0; k < rpi; ++k) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          t0[j] += red[(k * CW + cq) * 2 * V + j];
-          t1[j] += red[(k * CW + cq) * 2 * V + V + j];
-        }
+      for (int j = 0; j < V; ++j) {
+        t0[j] += red[(k * CW + cq) * 2 * V + j];
+        t1[j] += red[(k * CW + cq) * 2 * V + V + j];
       }
+    }
+    if (t.kind == NORM_TAIL_NONE) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         pout[c4 * V + j] = t0[j];
         if (NS == 2) pout[g.C + c4 * V + j] = t1[j];
       }
+    } else {                                           // handed to another workgroup of this launch: write-through
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        norm_st_sc1(pout + c4 * V + j, t0[j]);
+        if (NS == 2) norm_st_sc1(pout + g.C + c4 * V + j, t1[j]);
+      }
+    }
+  }
+  if (t.kind == NORM_TAIL_NONE) return;
+
+  // ---- level 1: the last workgroup of (sample n, this slice) sums the slice's chunks ---------------------------------------
+  if (!norm_arrive(t.ctr + n * g.slices + slice, (unsigned)g.chunks, tid, &s_flag)) return;
+  const int SC = CW * V;                               // channels of a slice (<= 128)
+  const int c_lo = slice * SC;
+  const int nout = NS * SC;                            // outputs (s, channel) of the slice: <= 256
+  int KG = 256 / nout;                                 // chunk groups summed side by side, then in order
+  {
+    const int o = tid % nout, kg = tid / nout;
+    const int sidx = o / SC, c = c_lo + o % SC;
+    double acc = 0.0;
+    if (kg < KG && c < g.C) {
+      // (plain loads behind the finisher's acquire; unrolled so that eight are in flight — the additions keep their order)
+      const double* src = part + ((size_t)n * g.chunks * 3 + sidx) * g.C + c;
+      const size_t kstride = (size_t)3 * g.C;
+#pragma unroll 8
+      for (int k = kg; k < g.chunks; k += KG) acc += src[k * kstride];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (kg == 0) {
+      double tot = 0.0;
+      for (int j = 0; j < KG; ++j) tot += red[j * nout + o];
+      red[256 + o] = tot;                              // sums[s][channel of the slice]
+      if (c < g.C) norm_st_sc1(t.nc + ((size_t)sidx * g.N + n) * g.C + c, tot);
+    }
+  }
+  // ---- level 2 ---------------------------------------------------------------------------------------------------------------
+  unsigned* const ctr2 = t.ctr + g.N * g.slices;
+  if (t.kind == NORM_TAIL_PS_FWD) {
+    if (!norm_arrive(ctr2 + n, (unsigned)g.slices, tid, &s_flag)) return;
+    // all slices of sample n are in nc: statistics of its groups (fixed order over the group's channels), then the tables
+    const int groups = (t.norm == MSEG_NORM_GN) ? 8 : g.C;
+    const int cg = g.C / groups;
+    const double* S = t.nc + (size_t)n * g.C;
+    const double* Q = t.nc + ((size_t)g.N + n) * g.C;
+    for (int base = 0; base < groups; base += 128) {   // 128 groups at a time through LDS: mean | rstd
+      const int grp = base + tid;
+      if (tid < 128 && grp < groups) {
+        double sm = 0.0, q = 0.0;
+        for (int k = 0; k < cg; ++k) { sm += S[grp * cg + k]; q += Q[grp * cg + k]; }
+        const double cnt = (double)cg * g.HW;
+        const double mean = sm / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)t.eps);
+        red[tid] = mean; red[128 + tid] = rstd;
+        t.mean_out[n * groups + grp] = (float)mean;
+        t.rstd_out[n * groups + grp] = (float)rstd;
+      }
+      __syncthreads();
+      const int c_end = (base + 128 < groups ? base + 128 : groups) * cg;
+      for (int c = base * cg + tid; c < c_end; c += 256) {
+        const int gl = c / cg - base;
+        const double mean = red[gl], rstd = red[128 + gl];
+        const double ga = (t.norm == MSEG_NORM_GN && t.gamma) ? (double)t.gamma[c] : 1.0;
+        const double be = (t.norm == MSEG_NORM_GN && t.beta) ? (double)t.beta[c] : 0.0;
+        t.scale[(size_t)n * g.C + c] = (float)(ga * rstd);
+        t.shift[(size_t)n * g.C + c] = (float)(be - mean * ga * rstd);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (!norm_arrive(ctr2 + slice, (unsigned)g.N, tid, &s_flag)) return;
+  // every sample of this slice is in nc: sums over the samples in index order, then the per-channel results
+  {
+    const int o = tid % nout;
+    const int sidx = o / SC, c = c_lo + o % SC;
+    if (tid < nout) {
+      double sm = 0.0;
+      if (c < g.C) {
+        const double* src = t.nc + (size_t)sidx * g.N * g.C + c;
+#pragma unroll 8
+        for (int i = 0; i < g.N; ++i) sm += src[(size_t)i * g.C];
+      }
+      red[o] = sm;
     }
     __syncthreads();
+    const int c2 = c_lo + tid;
+    if (tid < SC && c2 < g.C) {
+      const double a0 = red[tid], b0 = NS == 2 ? red[SC + tid] : 0.0;
+      const double cnt = (double)g.N * g.HW;
+      if (t.kind == NORM_TAIL_COLSUM) {
+        t.colsum[c2] = (float)a0;
+      } else if (t.kind == NORM_TAIL_BN_FWD) {
+        const double mean = a0 / cnt;
+        double var = b0 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)t.eps);
+        const double ga = t.gamma ? (double)t.gamma[c2] : 1.0, be = t.beta ? (double)t.beta[c2] : 0.0;
+        t.scale[c2] = (float)(ga * rstd);
+        t.shift[c2] = (float)(be - mean * ga * rstd);
+        t.mean_out[c2] = (float)mean;
+        t.rstd_out[c2] = (float)rstd;
+        if (t.running_mean) {
+          const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+          t.running_mean[c2] = (float)((1.0 - (double)t.momentum) * t.running_mean[c2] + (double)t.momentum * mean);
+          t.running_var[c2] = (float)((1.0 - (double)t.momentum) * t.running_var[c2] + (double)t.momentum * unb);
+        }
+      } else {                                         // NORM_TAIL_BN_BWD: a0 = sum gy, b0 = sum gy a
+        const double mu = t.mean[c2], r = t.rstd[c2], ga = t.gamma ? (double)t.gamma[c2] : 1.0;
+        const double sx = r * (b0 - mu * a0);          // sum gy * xhat
+        const double m1 = ga * a0 / cnt, m2 = ga * sx / cnt;
+        t.k1[c2] = (float)(ga * r);
+        t.k2[c2] = (float)(-r * r * m2);
+        t.k3[c2] = (float)(-r * m1 + r * r * m2 * mu);
+        if (t.dgamma) t.dgamma[c2] = (float)sx;
+        if (t.dbeta) t.dbeta[c2] = (float)a0;
+      }
+    }
   }
 }
 
@@ -412,16 +597,31 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
 
 #define NORM_PASS_A(MODE_, S16_, ...)                                                                                \
   do {                                                                                                               \
-    if (aio_) hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, true>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__, aio_); \
-    else hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, false>), dim3(g.chunks, N), dim3(256), 0, st, __VA_ARGS__, aio_);     \
+    if (aio_) hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, true>), dim3(g.chunks, N, g.slices), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((norm_pass_kernel<MODE_, S16_, false>), dim3(g.chunks, N, g.slices), dim3(256), 0, st, __VA_ARGS__);     \
   } while (0)
-// the last kernel argument (`aio`: stored activation, nullable) also selects the instantiation
+// AIO_ (`aio`: stored activation, nullable) also selects the instantiation; the kernel arguments follow
 #define NORM_PASS(MODE_, AIO_, ...)                                                                                  \
   do {                                                                                                               \
     auto aio_ = (AIO_);                                                                                              \
     if (st_ == MSEG_ST_BF16) NORM_PASS_A(MODE_, true, __VA_ARGS__);                                                  \
     else NORM_PASS_A(MODE_, false, __VA_ARGS__);                                                                     \
   } while (0)
+
+static int g_norm_tails = -1;          // -1: not set yet (MSEG_NORM_TAILS in the environment, else the default below)
+// Test / ablation hook: 1 = the last workgroups of a pass finish the reductions in the kernel, 0 = every pass is followed by
+// the separate reduction / finalize launches (same results, bit for bit)
+extern "C" int mseg_norm_set_tails(int on) {
+  g_norm_tails = on ? 1 : 0;
+  return MSEG_OK;
+}
+static bool norm_tails_fit(const NormGeom& g) {
+  if (g_norm_tails < 0) {
+    const char* e = getenv("MSEG_NORM_TAILS");
+    g_norm_tails = e ? (atoi(e) != 0) : 0;
+  }
+  return g_norm_tails && (long long)g.N * g.slices + (g.N > g.slices ? g.N : g.slices) <= NORM_CTR_MAX;
+}
 
 extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int act, int norm, const float* gamma,
                                const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
@@ -435,11 +635,17 @@ extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int
   if ((running_mean == nullptr) != (running_var == nullptr)) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
-  double* part = (double*)ws;
+  double* part = (double*)((char*)ws + NORM_CTR_BYTES);
   double* nc = part + (size_t)N * g.chunks * 3 * C;
+  NormTail t = {};
+  t.kind = norm_tails_fit(g) ? (norm == MSEG_NORM_BN ? NORM_TAIL_BN_FWD : NORM_TAIL_PS_FWD) : NORM_TAIL_NONE;
+  t.norm = norm; t.ctr = (unsigned*)ws; t.nc = nc; t.gamma = gamma; t.beta = beta; t.eps = eps; t.momentum = momentum;
+  t.scale = scale; t.shift = shift; t.mean_out = mean; t.rstd_out = rstd;
+  t.running_mean = running_mean; t.running_var = running_var;
   NORM_PASS(0, act_out, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
-            (const float*)nullptr, 0, g, act, part);
+            (const float*)nullptr, 0, g, act, part, aio_, t);
   MSEG_LAUNCH_CHECK();
+  if (t.kind != NORM_TAIL_NONE) return MSEG_OK;
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
   MSEG_LAUNCH_CHECK();
@@ -455,8 +661,9 @@ extern "C" int mseg_activation(const void* z, int N, int HW, int C, int st_, int
   if ((st_ != MSEG_ST_F32 && st_ != MSEG_ST_BF16) || (st_ == MSEG_ST_BF16 && (C & 7))) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
+  NormTail t = {};
   NORM_PASS(3, act_out, z, (const void*)nullptr, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
-            (const float*)nullptr, 0, g, act, (double*)nullptr);
+            (const float*)nullptr, 0, g, act, (double*)nullptr, aio_, t);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }
@@ -480,26 +687,38 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   if (norm == MSEG_NORM_GN && (C % 8)) return MSEG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   NormGeom g = norm_geom(N, HW, C, norm_vec(st_));
-  double* part = (double*)ws;
+  double* part = (double*)((char*)ws + NORM_CTR_BYTES);
   double* nc = part + (size_t)N * g.chunks * 3 * C;
   float* k1 = (float*)(nc + (size_t)3 * N * C);
   float* k2 = k1 + (size_t)N * C;
   float* k3 = k2 + (size_t)N * C;
   const int kss = (norm == MSEG_NORM_BN) ? 0 : C;
+  const bool tails = norm_tails_fit(g);
+  NormTail t = {};
+  // BatchNorm: the last workgroups of the sums pass write k1 / k2 / k3, dgamma, dbeta.  Group / InstanceNorm need the sums of
+  // a whole sample AND (dgamma, dbeta) of all samples: they keep the two small launches.
+  t.kind = (tails && norm == MSEG_NORM_BN) ? NORM_TAIL_BN_BWD : NORM_TAIL_NONE;
+  t.norm = norm; t.ctr = (unsigned*)ws; t.nc = nc; t.gamma = gamma; t.mean = mean; t.rstd = rstd;
+  t.k1 = k1; t.k2 = k2; t.k3 = k3; t.dgamma = dgamma; t.dbeta = dbeta;
   NORM_PASS(1, const_cast<void*>(act_in), z, gy, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
-            (const float*)nullptr, 0, g, act, part);
+            (const float*)nullptr, 0, g, act, part, aio_, t);
   MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
-                     (const double*)part, nc, g, 2);
-  MSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
-                     st, (const double*)nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta);
-  MSEG_LAUNCH_CHECK();
+  if (t.kind == NORM_TAIL_NONE) {
+    hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
+                       (const double*)part, nc, g, 2);
+    MSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
+                       st, (const double*)nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta);
+    MSEG_LAUNCH_CHECK();
+  }
   double* part2 = part;
+  NormTail t2 = {};
+  t2.kind = (tails && dbias) ? NORM_TAIL_COLSUM : NORM_TAIL_NONE;
+  t2.norm = norm; t2.ctr = (unsigned*)ws; t2.nc = nc; t2.colsum = dbias;
   NORM_PASS(2, const_cast<void*>(act_in), z, gy, dz, (const float*)k1, (const float*)k2, (const float*)k3, kss, g, act,
-            part2);
+            part2, aio_, t2);
   MSEG_LAUNCH_CHECK();
-  if (dbias) {
+  if (dbias && t2.kind == NORM_TAIL_NONE) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,
                        (const double*)part2, nc, g, 1);
     MSEG_LAUNCH_CHECK();

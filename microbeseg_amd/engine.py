@@ -83,10 +83,13 @@ class Workspace:
         self.device = device
         self.buf = {}
 
-    def get(self, name, nbytes):
+    def get(self, name, nbytes, zero=False):
+        """`zero`: a buffer whose head holds device-side counters the kernels keep at zero (mseg_norm_*): zero-filled
+        whenever it is (re)allocated"""
         b = self.buf.get(name)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            make = torch.zeros if zero else torch.empty
+            b = make(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
             self.buf[name] = b
         return b
 
@@ -595,7 +598,7 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
         node.mean = torch.empty(N * ng, dtype=torch.float32, device=dev)
         node.rstd = torch.empty(N * ng, dtype=torch.float32, device=dev)
         running_mean = running_var = None
-    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
+    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc), zero=True)
     check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
                               node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
                               node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
@@ -611,7 +614,7 @@ def norm_bwd(node, gy, gamma, dgamma, dbeta, dbias, ws):
     """gy (dL/d normalised output) -> dz in place; returns the same tensor holding dz."""
     lib = _lib.load()
     N, HW, Cc = node.N, node.H * node.W, node.C
-    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc))
+    w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc), zero=True)
     check(lib.mseg_norm_bwd(gy.data_ptr(), node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, node.norm, _ptr(gamma),
                             node.mean.data_ptr(), node.rstd.data_ptr(), gy.data_ptr(), _ptr(dgamma), _ptr(dbeta),
                             _ptr(dbias), _ptr(node.a), w.data_ptr(), _stream()), "norm_bwd")
@@ -680,6 +683,35 @@ class Tape:
         self.x4 = None
 
 
+class RawFrame:
+    """One raw uint8 / uint16 frame on the device, to be normalised and padded by the network's first kernel (K14 on the
+    device: reference infer.py:346-348 + utils.py:124-163).  `minmax`: int32[2] device tensor filled by `reduce_minmax`."""
+    PIX = {torch.uint8: 0, torch.uint16: 1, torch.int16: 1}      # (int16 storage of uint16 data: same bits)
+
+    def __init__(self, raw, pad_top=0, pad_left=0):
+        if raw.dim() != 2 or raw.dtype not in self.PIX or not raw.is_cuda or not raw.is_contiguous():
+            raise RuntimeError("RawFrame: a contiguous 2-D uint8 / uint16 CUDA tensor expected")
+        self.raw, self.pad_top, self.pad_left = raw, int(pad_top), int(pad_left)
+        self.minmax = torch.empty(2, dtype=torch.int32, device=raw.device)
+        self.H, self.W = raw.shape[0] + self.pad_top, raw.shape[1] + self.pad_left
+        check(_lib.load().mseg_frame_minmax(raw.data_ptr(), self.PIX[raw.dtype], raw.numel(), self.minmax.data_ptr(),
+                                            _stream()), "frame_minmax")
+
+    @property
+    def device(self):
+        return self.raw.device
+
+    def args(self):
+        return (self.raw.data_ptr(), self.PIX[self.raw.dtype], self.raw.shape[0], self.raw.shape[1], self.pad_top,
+                self.pad_left, self.minmax.data_ptr())
+
+    def normalized(self):
+        """the padded, normalised frame as an fp32 tensor (1, 1, H, W): first layers without the fused kernel, tests"""
+        out = torch.empty((1, 1, self.H, self.W), dtype=torch.float32, device=self.raw.device)
+        check(_lib.load().mseg_frame_normalize(*self.args(), out.data_ptr(), _stream()), "frame_normalize")
+        return out
+
+
 def _first_layer_ok(cin, cout, stride):
     return stride == 1 and 1 <= cin <= 4 and cout % 4 == 0 and cout <= 256 and 256 % (cout // 4) == 0
 
@@ -690,8 +722,11 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
     n0 = in_nodes[0]
     N, Hi, Wi = n0.N, n0.H, n0.W
     dev = n0.z.device
+    if isinstance(n0.z, RawFrame):
+        srcs = []
     cin_total = sum(n.C for n in in_nodes)
-    srcs = [n.src() for n in in_nodes]
+    if not isinstance(n0.z, RawFrame):
+        srcs = [n.src() for n in in_nodes]
     bias = conv.bias.detach()
     wt = conv.weight.detach()
     if spec.kind == "up":
@@ -712,7 +747,11 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
             assert _pad4(cin) == cin_total, (cin, cin_total)   # network input is zero-padded to 4 channels
         Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
         z = torch.empty((N, Ho, Wo, cout), dtype=st, device=dev)
-        if first_layer_cin is not None and _first_layer_ok(cin, cout, stride):
+        if first_layer_cin is not None and isinstance(n0.z, RawFrame):
+            # inference on a raw frame: normalisation and padding happen in this kernel's loads
+            check(_lib.load().mseg_first_conv_fwd_raw(*n0.z.args(), wt.contiguous().data_ptr(), bias.data_ptr(), cout,
+                                                      z.data_ptr(), _st(z), _stream()), "first_conv_fwd_raw")
+        elif first_layer_cin is not None and _first_layer_ok(cin, cout, stride):
             # raw network input, 9..36 MACs per output: HBM-bound VALU kernel instead of a 32-channel MFMA K-step
             check(_lib.load().mseg_first_conv_fwd(n0.z.data_ptr(), wt.contiguous().data_ptr(), bias.data_ptr(), N, Hi,
                                                   Wi, cin, cout, z.data_ptr(), _st(z), _stream()), "first_conv_fwd")
@@ -765,16 +804,31 @@ def forward(spec, x, training, keep_tape, ws):
     """x: (N, ch_in, H, W) fp32 CUDA tensor.  Returns (list of NCHW outputs, Tape|None)."""
     lib = _lib.load()
     del _nbt_pending[:]
-    N, cin, H, W = x.shape
+    raw = x if isinstance(x, RawFrame) else None
+    if raw is not None:
+        # a raw frame (inference): fused into the first convolution when that layer takes the row-walking VALU kernel,
+        # else normalised into an fp32 tensor by one streaming kernel
+        c1 = spec.enc[0]["c1"].conv.weight
+        fused = (not keep_tape and c1.shape[1] == 1 and c1.shape[0] % 8 == 0 and c1.shape[0] <= 256 and
+                 256 % (c1.shape[0] // 8) == 0)
+        if not fused:
+            x, raw = raw.normalized(), None
+    if raw is not None:
+        N, cin, H, W = 1, 1, raw.H, raw.W
+    else:
+        N, cin, H, W = x.shape
     nlev = len(spec.enc)
     div = 2 ** (nlev - 1)
     if H % div or W % div:
         raise RuntimeError(f"input {H}x{W} is not divisible by {div}")
     dev = x.device
     c4 = _pad4(cin)
-    x4 = torch.zeros((N, H, W, c4), dtype=torch.float32, device=dev)
-    x4[..., :cin] = x.detach().permute(0, 2, 3, 1)
-    xin = Node(x4, N, H, W, c4)
+    if raw is not None:
+        xin = Node(raw, N, H, W, c4)
+    else:
+        x4 = torch.zeros((N, H, W, c4), dtype=torch.float32, device=dev)
+        x4[..., :cin] = x.detach().permute(0, 2, 3, 1)
+        xin = Node(x4, N, H, W, c4)
     tape = Tape() if keep_tape else None
     if tape is not None:
         tape.x4 = xin
@@ -967,6 +1021,9 @@ class _NetFunction(torch.autograd.Function):
 
 def run_module(module, x):
     """Entry used by UNet/DUNet.forward: returns a tuple of NCHW outputs."""
+    if isinstance(x, RawFrame):                      # inference on a raw frame (never differentiated)
+        outs, _ = forward(module._spec, x, module.training, False, module._workspace(x.device))
+        return tuple(outs)
     if not x.is_cuda:
         raise RuntimeError(
             "microbeseg_amd: the U-Net runs on the MI355X HIP path only (got a CPU tensor); there is deliberately "

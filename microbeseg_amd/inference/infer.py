@@ -123,6 +123,8 @@ class InferWorker(QObject):
         """network forward of one padded frame; None (after the reference's message) if it does not fit in memory"""
         try:
             with engine.precision_scope(self.precision):
+                if isinstance(img_batch, engine.RawFrame):      # raw frame on the device: normalised by the first kernel
+                    return self.net(img_batch)
                 if self.sliding_window:
                     from .tiling import tiled_forward
                     return tiled_forward(self.net, img_batch.to(self.device), tile=self.tile_size)
@@ -185,35 +187,70 @@ class InferWorker(QObject):
                 results[f] = host.numpy().view(np.uint16)
             self.progress.emit(int(100 * (f + 1) / len(img)))
 
+        def launch_postproc(frame, pred, pads):
+            border, cell = pred
+            cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
+            border = border[0, 0, pads[0]:, pads[1]:].contiguous()
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1],
+                                                                 th_cell=self.ths[0], col_major_ids=True)
+                border.record_stream(side)
+                cell.record_stream(side)
+                host = torch.empty(labels.shape, dtype=torch.int16, pin_memory=True)
+                host.copy_(labels, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            pending.append((frame, host, done))
+
+        # K14 on the device (uint8 / uint16 stacks, whole-frame inference): the raw frame goes up from a pinned staging
+        # buffer on a copy stream, its extrema are reduced on the device and the first convolution normalises / pads while it
+        # loads (engine.RawFrame) — the host loop only copies into pinned memory and enqueues.  Same input values bit for
+        # bit as the host formula of inference() (tests/test_gpu_fullsize.py), so the masks are identical.
+        device_norm = (img.dtype in (np.uint8, np.uint16) and not self.sliding_window and img.shape[1] <= 8192
+                       and img.shape[2] <= 8192)
         with torch.cuda.device(self.device), torch.no_grad():
+            if device_norm:
+                from ..utils.utils import pad_amounts
+                pads = pad_amounts(img.shape[1:])
+                tdt = torch.uint8 if img.dtype == np.uint8 else torch.int16      # (uint16 bits in int16 storage)
+                stage = [torch.empty(img.shape[1:], dtype=tdt, pin_memory=True) for _ in range(2)]
+                raw_dev = [torch.empty(img.shape[1:], dtype=tdt, device=self.device) for _ in range(2)]
+                uploaded = [None, None]          # copy-stream events: staging buffer k has left the host
+                consumed = [None, None]          # main-stream events: the network has read device buffer k
+                copy_stream = torch.cuda.Stream(device=self.device)
+                main = torch.cuda.current_stream()
             for frame in range(len(img)):
                 if self.stop_inference:
                     break
-                img_frame = np.copy(img[frame])
-                frame_min, frame_max = np.min(img_frame), np.max(img_frame)
-                img_frame, pads = self.pad_frame(img_frame, frame_min)
-                img_batch = 2 * (img_frame.astype(np.float32) - frame_min) / (frame_max - frame_min) - 1
-                img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
-                pred = self._forward(img_batch)
+                if device_norm:
+                    k = frame & 1
+                    if uploaded[k] is not None:
+                        uploaded[k].synchronize()            # the staging buffer is free again
+                    np.copyto(stage[k].numpy().view(img.dtype), img[frame])
+                    with torch.cuda.stream(copy_stream):
+                        if consumed[k] is not None:
+                            copy_stream.wait_event(consumed[k])
+                        raw_dev[k].copy_(stage[k], non_blocking=True)
+                        uploaded[k] = torch.cuda.Event()
+                        uploaded[k].record(copy_stream)
+                    main.wait_event(uploaded[k])
+                    pred = self._forward(engine.RawFrame(raw_dev[k], pads[0], pads[1]))
+                    consumed[k] = torch.cuda.Event()
+                    consumed[k].record(main)
+                else:
+                    img_frame = np.copy(img[frame])
+                    frame_min, frame_max = np.min(img_frame), np.max(img_frame)
+                    img_frame, pads = self.pad_frame(img_frame, frame_min)
+                    img_batch = 2 * (img_frame.astype(np.float32) - frame_min) / (frame_max - frame_min) - 1
+                    img_batch = torch.from_numpy(np.ascontiguousarray(img_batch[None, None, :, :])).to(torch.float)
+                    pred = self._forward(img_batch)
                 if pred is None:                 # out of memory: zero mask, like inference() (infer.py:354-356)
                     pending.append((frame, None, None))
                 else:
-                    border, cell = pred
-                    cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
-                    border = border[0, 0, pads[0]:, pads[1]:].contiguous()
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1],
-                                                                         th_cell=self.ths[0], col_major_ids=True)
-                        border.record_stream(side)
-                        cell.record_stream(side)
-                        host = torch.empty(labels.shape, dtype=torch.int16, pin_memory=True)
-                        host.copy_(labels, non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(side)
-                    pending.append((frame, host, done))
+                    launch_postproc(frame, pred, pads)
                 while len(pending) > 2:          # two frames in flight
                     finish(pending.pop(0))
             while pending:

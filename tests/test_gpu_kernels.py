@@ -268,6 +268,94 @@ def test_norm_forward_backward(eng, norm, act, N, Cc, H, W):
         assert rel_err(dbeta.cpu(), beta.grad) < TOL
 
 
+@pytest.mark.parametrize("st", ["f32", "bf16"])
+@pytest.mark.parametrize("norm", ["bn", "gn", "in"])
+@pytest.mark.parametrize("N,Cc,H,W", [(4, 64, 96, 96), (9, 256, 40, 40), (32, 1024, 12, 10), (2, 72, 33, 31), (33, 128, 64, 64)])
+def test_norm_tails_equal_separate_launches(eng, st, norm, N, Cc, H, W):
+    """The last workgroups of a normalisation pass finish the reductions over chunks / samples and write the tables
+    (mseg_norm_set_tails(1), the default): every output — tables, saved statistics, running statistics, dz, dgamma, dbeta,
+    dbias — is BIT-identical to the path with the separate reduction / finalize launches, call after call on one
+    workspace (the arrival counters return to zero), for one to many chunks, channel slices and samples."""
+    from microbeseg_amd import _lib
+    from microbeseg_amd._lib import ACT, NORM
+    lib = _lib.load()
+    if st == "bf16" and Cc % 8:
+        pytest.skip("bf16 storage: 8 channels per thread")
+    dt = torch.bfloat16 if st == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(91 + Cc + N)
+    z = (rnd(g, N, H, W, Cc) * 1.5 + 0.3).cuda().to(dt)
+    gy = rnd(g, N, H, W, Cc).cuda().to(dt)
+    gamma, beta = (rnd(g, Cc) * 0.3 + 1).cuda(), (rnd(g, Cc) * 0.1).cuda()
+    has_aff = norm != "in"
+    ws = eng.Workspace(torch.device("cuda"))
+    results = []
+    for mode in (1, 0, 1):
+        assert lib.mseg_norm_set_tails(mode) == 0
+        try:
+            node = eng.Node(z, N, H, W, Cc)
+            node.act = ACT["relu"]
+            rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+            eng.norm_stats(node, NORM[norm], gamma if has_aff else None, beta if has_aff else None,
+                           rm if norm == "bn" else None, rv if norm == "bn" else None, True, ws)
+            dgamma = torch.empty(Cc, device="cuda") if has_aff else None
+            dbeta = torch.empty(Cc, device="cuda") if has_aff else None
+            dbias = torch.empty(Cc, device="cuda")
+            dz = eng.norm_bwd(node, gy.clone(), gamma if has_aff else None, dgamma, dbeta, dbias, ws)   # (dz may alias gy)
+            torch.cuda.synchronize()
+            out = [node.scale, node.shift, node.mean, node.rstd, rm, rv, dz.float(), dbias]
+            if has_aff:
+                out += [dgamma, dbeta]
+            results.append([o.clone() for o in out])
+        finally:
+            lib.mseg_norm_set_tails(1)
+    for k, (a, b, c) in enumerate(zip(*results)):
+        assert torch.isfinite(a).all(), k
+        assert torch.equal(a, b), f"output {k}: tails differ from the separate launches"
+        assert torch.equal(a, c), f"output {k}: second call on the same workspace differs"
+    # the counters are back at zero
+    head = ws.buf["norm"][:65536].view(torch.int32)
+    assert int(head.abs().max().item()) == 0
+
+
+@pytest.mark.parametrize("dtype,H0,W0", [(np.uint16, 100, 90), (np.uint8, 64, 64), (np.uint16, 333, 257), (np.uint16, 256, 320)])
+def test_frame_normalisation_on_the_device(eng, dtype, H0, W0):
+    """K14 on the device: min / max of a raw frame, top / left padding to the tested shapes and
+    2 * (f32(x) - min) / (max - min) - 1 (reference infer.py:346-348, utils.py:124-163) — the normalised frame equals the
+    host formula BIT FOR BIT, and the first convolution fed with the raw frame equals, bit for bit, the same convolution fed
+    with the host-normalised tensor."""
+    from microbeseg_amd import _lib
+    from microbeseg_amd.utils.utils import zero_pad_model_input
+    lib = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(5 + H0))
+    hi = 255 if dtype == np.uint8 else 60000
+    frame = rng.integers(7, hi, size=(H0, W0)).astype(dtype)
+    fmin, fmax = np.min(frame), np.max(frame)
+    padded, pads = zero_pad_model_input(np.copy(frame), pad_val=fmin)
+    want = 2 * (padded.astype(np.float32) - fmin) / (fmax - fmin) - 1          # the reference's expression, numpy scalars
+    store = torch.from_numpy(frame.view(np.int16) if dtype == np.uint16 else frame).cuda()
+    rf = eng.RawFrame(store, pads[0], pads[1])
+    mm = rf.minmax.cpu().numpy().view(np.uint32)
+    assert (~mm[0]) & 0xffffffff == int(fmin) and mm[1] == int(fmax)
+    got = rf.normalized().cpu().numpy()[0, 0]
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32))
+    # fused into the first convolution
+    g = torch.Generator().manual_seed(3)
+    Cout = 64
+    w, b = (rnd(g, Cout, 1, 3, 3) * 0.3).cuda(), rnd(g, Cout).cuda()
+    H, W = want.shape
+    for st in (torch.float32, torch.bfloat16):
+        z_raw = torch.full((1, H, W, Cout), float("nan"), device="cuda", dtype=st)
+        _lib.check(lib.mseg_first_conv_fwd_raw(*rf.args(), w.data_ptr(), b.data_ptr(), Cout, z_raw.data_ptr(), eng._st(z_raw),
+                                               torch.cuda.current_stream().cuda_stream), "first_conv_fwd_raw")
+        x4 = torch.zeros((1, H, W, 4), device="cuda")
+        x4[..., 0] = torch.from_numpy(want.astype(np.float32)).cuda()
+        z_ref = torch.full((1, H, W, Cout), float("nan"), device="cuda", dtype=st)
+        _lib.check(lib.mseg_first_conv_fwd(x4.data_ptr(), w.data_ptr(), b.data_ptr(), 1, H, W, 1, Cout, z_ref.data_ptr(),
+                                           eng._st(z_ref), torch.cuda.current_stream().cuda_stream), "first_conv_fwd")
+        assert torch.equal(z_raw.float(), z_ref.float())
+
+
 def test_bn_eval_coeffs(eng):
     from microbeseg_amd._lib import NORM
     g = torch.Generator().manual_seed(1)
@@ -703,7 +791,7 @@ def test_bf16_storage_norm_forward_backward(eng, norm, act):
     scale, shift = torch.empty(nsc, device="cuda"), torch.empty(nsc, device="cuda")
     mean, rstd = torch.empty(ng, device="cuda"), torch.empty(ng, device="cuda")
     aout = torch.empty_like(zd) if act == "mish" else None
-    ws = torch.empty(lib.mseg_norm_workspace_bytes(N, H * W, Cc), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(lib.mseg_norm_workspace_bytes(N, H * W, Cc), dtype=torch.uint8, device="cuda")   # counters: zero once
     st = torch.cuda.current_stream().cuda_stream
     gd, bd = (gamma.cuda(), beta.cuda()) if norm != "in" else (None, None)
     P = lambda t: None if t is None else t.data_ptr()
