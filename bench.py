@@ -194,16 +194,35 @@ def cpu_baseline(args, filters):
     return out
 
 
+def _boundary_probs(cell, border):
+    """softmax-like (H, W, 3) probabilities of the boundary method from synthetic cell / border maps"""
+    import numpy as np
+    p1 = np.clip(cell * 2.0, 0, 1) * (1 - np.clip(border * 1.2, 0, 1))
+    p2 = np.clip(border * 1.2, 0, 1) * (cell > 0.02)
+    p0 = np.clip(1 - p1 - p2, 0.0, 1)
+    probs = np.stack([p0, p1, p2], -1).astype(np.float32)
+    return probs / probs.sum(-1, keepdims=True)
+
+
 def inference_metric(args, net, dev):
     """Secondary metric of BASELINE.json: inference Mpixels/s including the watershed, 1 GPU, configs[4] shape
-    (2048x2048 frames, DU-Net [64,1024], batch 1).  Random weights give meaningless seeds, so the
-    network forward is timed on the frame and the post-processing on synthetic prediction maps (~2500 cells/frame)
-    that stay in HBM.  `value` is the throughput of a T-frame stack processed the way InferWorker.infer_stack does it:
-    the watershed of frame i on a side stream while the network runs frame i+1 (wall clock over T frames, both
-    streams drained); `serial_Mpx_s` = pixels / (t_net + t_postproc) of one frame at a time.  CPU side: the C oracle of
-    the post-processing, single thread like scipy/scikit-image, on the same maps."""
+    (2048x2048 2D+t stack, DU-Net [64,1024]).
+
+    `value` = wall clock of the PRODUCT path: `InferWorker.infer_stack` (infer_script_local.py:118-161) on a
+    [T, S, S] uint16 stack in host memory with a checkpoint written to a temporary directory — staging into pinned memory,
+    upload, min / max + normalisation + padding (on the device, K14), network, watershed on the side stream, download of
+    the masks; the same again with the opt-in bf16 network (`bf16`).  An untrained network predicts no distance maps, so the
+    two thresholds are taken from the distribution of its own output on frame 0 (~15 % cell pixels, ~4 % seed pixels:
+    thousands of instances per frame, `instances`).
+    Next to it, on tensors resident in HBM: `net_ms` (one frame through the network), `postproc_ms` on synthetic prediction
+    maps with ~2500 cells (labels checked bit for bit against the C oracle), `boundary_postproc` (the boundary method's
+    post-processing, reference postprocessing.py:62-90) and the C oracle on one host core."""
+    import json as _json
+    import tempfile
     import numpy as np
+    from microbeseg_amd import engine
     from microbeseg_amd.inference import postprocessing as pp
+    from microbeseg_amd.inference.infer import InferWorker
     from microbeseg_amd.utils import synth
     from oracle import postproc_ref
     S, T = args.infer_size, args.infer_frames
@@ -213,44 +232,94 @@ def inference_metric(args, net, dev):
     c, b = torch.from_numpy(cell).to(dev), torch.from_numpy(border).to(dev)
     frame = (torch.rand(1, 1, S, S, device=dev) * 2 - 1)
     net.eval()
+    n_res = min(T, 8)
+    net_ms = {}
     with torch.no_grad():
-        net(frame)
+        for prec in ("fp32", "bf16"):
+            with engine.precision_scope(prec):
+                net(frame)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n_res):
+                    net(frame)
+                e1.record()
+                torch.cuda.synchronize()
+                net_ms[prec] = e0.elapsed_time(e1) / n_res
         pp.distance_postprocessing_device(b, c, 0.45, 0.10)
         torch.cuda.synchronize()
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record()
-        for _ in range(T):
-            net(frame)
-        e[1].record()
-        for _ in range(T):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_res):
             labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
-        e[2].record()
+        e1.record()
         torch.cuda.synchronize()
-        # pipelined stack: network on the current stream, post-processing of the previous frame on a side stream
-        side = torch.cuda.Stream(device=dev)
-        t0 = time.perf_counter()
-        for _ in range(T):
-            net(frame)
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                labels, n_inst, status = pp.distance_postprocessing_device(b, c, 0.45, 0.10)
+        t_pp = e0.elapsed_time(e1) / n_res
+        probs = torch.from_numpy(_boundary_probs(cell, border)).to(dev)
+        pp.boundary_postprocessing_device(probs)
         torch.cuda.synchronize()
-        t_stack = (time.perf_counter() - t0) / T * 1e3
-    net.train()
-    t_net, t_pp = e[0].elapsed_time(e[1]) / T, e[1].elapsed_time(e[2]) / T
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            bl, bn, bs = pp.boundary_postprocessing_device(probs)
+        e1.record()
+        torch.cuda.synchronize()
+        t_bpp = e0.elapsed_time(e1) / 3
     t0 = time.perf_counter()
     want = postproc_ref.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
     t_cpu = time.perf_counter() - t0
     exact = bool(np.array_equal(labels.cpu().numpy().view(np.uint16), want))
-    return {"metric": "inference Mpixels/sec incl. watershed", "value": round(S * S / t_stack / 1e3, 2),
-            "unit": "Mpx/s", "frame": f"{S}x{S}", "frames": T, "stack_ms_per_frame": round(t_stack, 2),
-            "serial_Mpx_s": round(S * S / (t_net + t_pp) / 1e3, 2), "net_ms": round(t_net, 2),
+    want_b = postproc_ref.boundary_postprocessing(probs.cpu().numpy())
+    exact_b = bool(np.array_equal(bl.cpu().numpy().view(np.uint16), want_b))
+
+    # ---- the product path ------------------------------------------------------------------------------------------------
+    frames = []
+    for _ in range(2):                                   # two distinct synthetic frames, repeated over the stack
+        cm, _ = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2), rmin=5.0, rmax=13.0)
+        frames.append(np.clip(cm * 50000 + rng.normal(0, 800, cm.shape), 0, 65535).astype(np.uint16))
+    stack = np.stack([frames[t & 1] for t in range(T)])
+    product = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        base = os.path.join(tmp, "distance_model_00")
+        torch.save(net.state_dict(), base + ".pth")
+        with open(base + ".json", "w") as f:
+            _json.dump({"architecture": [args.arch, "conv", args.act, args.norm, list(args.filters)], "label_type": "distance"}, f)
+        worker = InferWorker(model=base, device=str(dev), ths=(0.10, 0.45))
+        f0 = stack[0]
+        with torch.no_grad():
+            x0 = torch.from_numpy((2 * (f0.astype(np.float32) - f0.min()) / (f0.max() - f0.min()) - 1)[None, None]).to(dev)
+            bo, ce = worker.net(x0)
+            bb = torch.tan(bo[0, 0].clamp(0, 1) ** 2)
+            bb = torch.where(bb < 0.05, torch.zeros_like(bb), bb).clamp(0, 1)
+            sub = slice(None, None, 7)
+            worker.ths = [float(torch.quantile(ce[0, 0][sub, sub].flatten(), 0.85)),
+                          float(torch.quantile((ce[0, 0] - bb)[sub, sub].flatten(), 0.96))]
+            del x0, bo, ce, bb
+        for prec in ("fp32", "bf16"):
+            worker.precision = prec
+            worker.infer_stack(stack[:2])                # warm-up (buffers, weight packs of this precision)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            masks = worker.infer_stack(stack)
+            dt = time.perf_counter() - t0
+            product[prec] = {"value": round(T * S * S / dt / 1e6, 2), "unit": "Mpx/s", "ms_per_frame": round(1e3 * dt / T, 2),
+                             "instances_frame0": int(masks[0].max()), "net_ms": round(net_ms[prec], 2)}
+        del worker
+    net.train()
+    main = product[args.precision]
+    return {"metric": "inference Mpixels/sec incl. watershed", "value": main["value"],
+            "unit": "Mpx/s", "frame": f"{S}x{S}", "frames": T, "stack_ms_per_frame": main["ms_per_frame"],
+            "path": "InferWorker.infer_stack on a host uint16 stack (staging, H2D, device min/max + normalise + pad, network, "
+                    "watershed, D2H of the masks); thresholds from the untrained network's own output quantiles",
+            "instances_frame0": main["instances_frame0"],
+            "serial_Mpx_s": round(S * S / (net_ms[args.precision] + t_pp) / 1e3, 2), "net_ms": round(net_ms[args.precision], 2),
             "postproc_ms": round(t_pp, 2),
             "net_precision": args.precision,
+            "bf16": product["bf16"], "fp32": product["fp32"],
             "postproc_Mpx_s": round(S * S / t_pp / 1e3, 1), "instances": int(n_inst), "postproc_status": int(status),
             "labels_bit_exact_vs_oracle": exact,
+            "boundary_postproc": {"value": round(S * S / t_bpp / 1e3, 1), "unit": "Mpx/s", "ms": round(t_bpp, 2),
+                                  "instances": int(bn), "status": int(bs), "labels_bit_exact_vs_oracle": exact_b},
             "cpu_postproc": {"value": round(S * S / t_cpu / 1e6, 2), "unit": "Mpx/s", "cores": 1, "kind": "port",
                              "sample": "1 frame through oracle/postproc_ref.c (single thread, like scipy/skimage)"}}
 
@@ -271,6 +340,19 @@ _LEGACY_PROFILE_CONFIG = {
 }
 
 
+def csrc_digest():
+    """sha1 over the kernel sources: a committed counter profile describes the kernels of exactly one such tree"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "microbeseg_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "microbeseg_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the newest committed TCC-counter profile OF THIS WORKLOAD
     (tools/pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied; the
@@ -278,19 +360,28 @@ def pmc_traffic(kernel, args):
     precision is used).  bench.py cannot collect PMC counters itself; the profile is part of the repo."""
     import glob
     want = workload_key(args)
+    sha = csrc_digest()
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")), reverse=True)
+    stale = None
     for f in files:
         tab = json.load(open(f))
         cfg = tab.get("__config__")
         if cfg is None:
             cfg = _LEGACY_PROFILE_CONFIG.get(os.path.basename(f)[:-len("_hbm_traffic_pmc.json")])
+        cfg = dict(cfg or {})
+        prof_sha = cfg.pop("csrc_sha", None)
         if cfg != want:
             continue
         ent = tab.get(kernel)
         if ent is None:
             continue
+        if prof_sha != sha:                              # measured on other kernel sources: not presented as current
+            stale = stale or os.path.basename(f)
+            continue
         return {"traffic": int(ent["hbm_bytes_per_launch"]), "traffic_unit": "bytes/launch (avg)",
-                "traffic_source": "profiles/" + os.path.basename(f)}
+                "traffic_source": "profiles/" + os.path.basename(f), "traffic_kernel": kernel}
+    if stale:
+        return {"traffic": None, "traffic_source": "stale", "traffic_stale_profile": "profiles/" + stale}
     return {"traffic": None, "traffic_source": "none"}
 
 
@@ -375,9 +466,10 @@ def train_metric(args, dev, world, rank, timing=True):
 
     for i in range(warmup):
         step(i)
-    # bf16 steps are short enough (32-50 ms) that the ~1300 event records of the kernel bracketing make them host-bound:
-    # there `value` comes from K un-bracketed steps and the kernel table / roofline from K more, bracketed steps
-    two_pass = timing and args.precision == "bf16"
+    # the ~1300 event records + dispatch queries of the kernel bracketing cost a few ms per step (bf16 steps of 30-50 ms
+    # become host-bound): `value` comes from K un-bracketed steps and the kernel table / roofline from K more, bracketed
+    # steps
+    two_pass = timing
     prof = engine.KernelTimer() if timing else None
     engine.set_kernel_timer(None if two_pass else prof)
     fence()
@@ -441,13 +533,30 @@ def train_metric(args, dev, world, rank, timing=True):
     if prof is not None:
         kernels = prof.summary()
         if kernels:
-            dom = max(kernels.values(), key=lambda k: k["total_ms"])
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(dom["tflops"], 2),
-                               "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / peak, 4), "traffic": None,
-                               "avg_launch_ms": round(dom["avg_ms"], 4), "launches": dom["launches"]}
-            out["roofline"].update(pmc_traffic(dom["kernel"], args))
+            # the dominant kernel FAMILY (all template instantiations of one kernel: they are one piece of code with
+            # compile-time branches, and a layer stack spreads over several of them)
+            fams = {}
+            for k, v in kernels.items():
+                fam = fams.setdefault(k.split("<")[0], {"family": k.split("<")[0], "total_ms": 0.0, "flops": 0.0, "launches": 0,
+                                                         "members": []})
+                fam["total_ms"] += v["total_ms"]
+                fam["flops"] += v["flops"]
+                fam["launches"] += v["launches"]
+                fam["members"].append(k)
+            dom = max(fams.values(), key=lambda f: f["total_ms"])
+            dom_tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            big = max(dom["members"], key=lambda k: kernels[k]["total_ms"])
+            peak = PEAK_BF16_MFMA_TFLOPS if ("bf16" in dom["family"] or "p8" in dom["family"]) else PEAK_FP32_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": dom["family"], "instantiations": sorted(dom["members"]),
+                               "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(dom_tf / peak, 4), "traffic": None,
+                               "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
+                               "ms_per_step": round(dom["total_ms"] / args.steps, 3)}
+            out["roofline"].update(pmc_traffic(big, args))
+            out["kernel_families"] = {f["family"]: {"tflops": round(f["flops"] / (f["total_ms"] * 1e-3) / 1e12, 2),
+                                                     "total_ms_per_step": round(f["total_ms"] / args.steps, 3),
+                                                     "launches_per_step": f["launches"] // args.steps}
+                                      for f in sorted(fams.values(), key=lambda f: -f["total_ms"])}
             out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "total_ms_per_step": round(v["total_ms"] / args.steps, 3),
                                   "avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] // args.steps}
                               for k, v in kernels.items()}
@@ -492,10 +601,16 @@ def main():
     out, net = train_metric(args, dev, world, rank, timing=not args.no_kernel_timing)
     headline = workload_key(args) == {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn",
                                       "filters": [64, 1024], "optimizer": "adam", "precision": "fp32"}
+    del net
     if rank == 0 and world == 1 and not args.no_inference and args.arch == "DU":
         torch.cuda.empty_cache()
-        out["inference"] = inference_metric(args, net, dev)
-    del net
+        # a freshly initialised network (fixed seed): the few optimisation steps above on random labels leave a network whose
+        # outputs are nearly constant, i.e. frames without seeds and a watershed with nothing to do
+        from microbeseg_amd.utils.unets import build_unet
+        torch.manual_seed(3)
+        net_i = build_unet(args.arch, args.act, "conv", args.norm, dev, 1, ch_out=1, filters=tuple(args.filters))
+        out["inference"] = inference_metric(args, net_i, dev)
+        del net_i
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and headline and not args.no_bf16_block:
         # BASELINE configs[2] next to the fp32 headline, so that the driver's default run records it too
@@ -508,6 +623,24 @@ def main():
         torch.cuda.empty_cache()
         engine.set_precision(args.precision)
         out["bf16_320"] = blk
+        # further configurations of the path, each a short run with its own roofline: the boundary method's
+        # U-Net with ce_dice, GroupNorm (the north-star's norm), the GUI / CLI default batch of 4
+        out["secondary"] = {}
+        for tag, kw in (("unet_ce_dice_bf16_256", dict(arch="U", precision="bf16")),
+                        ("groupnorm_bf16_320", dict(norm="gn", precision="bf16", size=320)),
+                        ("batch4_fp32_256", dict(batch=4)),
+                        ("batch4_bf16_256", dict(batch=4, precision="bf16"))):
+            a3 = copy.copy(args)
+            a3.graph = False
+            a3.steps, a3.warmup = 6, 3
+            for k_, v_ in kw.items():
+                setattr(a3, k_, v_)
+            blk, net3 = train_metric(a3, dev, 1, 0, timing=not args.no_kernel_timing)
+            del net3
+            torch.cuda.empty_cache()
+            blk.pop("kernels", None)                     # the per-instantiation table stays with the two main blocks
+            out["secondary"][tag] = blk
+        engine.set_precision(args.precision)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, tuple(args.filters))
     if world > 1:

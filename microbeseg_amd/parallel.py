@@ -35,25 +35,82 @@ def barrier():
         dist.barrier()
 
 
+_FORCE_COLLECTIVES = False     # tests: run the collective path with a group of ONE rank (the real backend executes it)
+
+
+def collectives_on():
+    return world_size() > 1 or (_FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
+def _arena_span(t):
+    """(arena, first element, one past the last element) if `t` is a contiguous view of a flat 1-D arena tensor (the
+    gradient views training/optim.FusedAdam hands out), else None"""
+    base = t._base
+    if base is None or base.dim() != 1 or not t.is_contiguous() or base.dtype != t.dtype:
+        return None
+    lo = t.storage_offset() - base.storage_offset()
+    return base, lo, lo + t.numel()
+
+
 class GradBucketer:
-    """Collects gradient tensors as the backward pass produces them, all-reduces them in flat buckets
-    asynchronously (RCCL stream), and averages them in place at ``finish()``.  Backend agnostic (gloo in tests)."""
+    """Collects gradient tensors as the backward pass produces them, all-reduces them asynchronously (RCCL stream) in
+    buckets of ~``bucket_bytes`` and averages them at ``finish()``.  Backend agnostic (gloo in tests).
+
+    Gradients that are views of a flat arena (``FusedAdam``: all gradients of the network live in ONE fp32 buffer, in
+    parameter order) are reduced IN PLACE: the backward pass produces them from the last layer to the first, i.e. the
+    finished part of the arena is a growing tail, and every bucket is one contiguous slice of it — no ``torch.cat``, no
+    copy back, one ``mul_`` over the arena at the end.  Other gradients (stock optimizers) go through a packed copy."""
+
+    GAP = 4            # arena views are 16-byte aligned: up to 3 padding floats between two neighbours
 
     def __init__(self, bucket_bytes=BUCKET_BYTES, group=None):
         self.bucket_bytes = bucket_bytes
         self.group = group
-        self.pending = []      # tensors of the bucket being filled
+        self.pending = []      # loose tensors of the bucket being filled
         self.pending_bytes = 0
-        self.inflight = []     # (flat buffer, [tensors], work handle)
+        self.inflight = []     # (flat buffer, [tensors] or None for an arena slice, work handle)
+        self.arenas = {}       # id(arena) -> [arena, sorted list of ready [lo, hi) spans not launched yet]
 
     def add(self, tensors):
         for t in tensors:
             if t is None:
                 continue
-            self.pending.append(t)
-            self.pending_bytes += t.numel() * t.element_size()
+            span = _arena_span(t)
+            if span is None:
+                self.pending.append(t)
+                self.pending_bytes += t.numel() * t.element_size()
+                continue
+            arena, lo, hi = span
+            ent = self.arenas.setdefault(id(arena), [arena, []])
+            self._insert(ent[1], lo, hi)
+            self._launch_arena(ent, force=False)
         if self.pending_bytes >= self.bucket_bytes:
             self._launch()
+
+    def _insert(self, spans, lo, hi):
+        """merge [lo, hi) into the sorted span list (neighbours up to GAP - 1 elements apart are joined: padding)"""
+        spans.append([lo, hi])
+        spans.sort()
+        merged = [spans[0]]
+        for s in spans[1:]:
+            if s[0] - merged[-1][1] < self.GAP:
+                merged[-1][1] = max(merged[-1][1], s[1])
+            else:
+                merged.append(s)
+        spans[:] = merged
+
+    def _launch_arena(self, ent, force):
+        arena, spans = ent
+        esz = arena.element_size()
+        keep = []
+        for lo, hi in spans:
+            if force or (hi - lo) * esz >= self.bucket_bytes:
+                view = arena[lo:hi]
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.inflight.append((view, None, work))
+            else:
+                keep.append([lo, hi])
+        spans[:] = keep
 
     def _launch(self):
         if not self.pending:
@@ -64,23 +121,53 @@ class GradBucketer:
         self.inflight.append((flat, tensors, work))
 
     def finish(self):
-        """Wait for all buckets and write the averaged gradients back into the original tensors."""
+        """Wait for all buckets; the averaged gradients are in the original tensors afterwards."""
         self._launch()
+        for ent in self.arenas.values():
+            self._launch_arena(ent, force=True)
         inv = 1.0 / dist.get_world_size(self.group)
         for flat, tensors, work in self.inflight:
             work.wait()
-            flat.mul_(inv)
-            off, views = 0, []
-            for t in tensors:
-                n = t.numel()
-                views.append(flat[off:off + n].view_as(t))
-                off += n
-            torch._foreach_copy_(tensors, views)      # one multi-tensor launch per bucket
+            flat.mul_(inv)                             # an arena slice: in place, done
+            if tensors is not None:
+                off, views = 0, []
+                for t in tensors:
+                    n = t.numel()
+                    views.append(flat[off:off + n].view_as(t))
+                    off += n
+                torch._foreach_copy_(tensors, views)      # one multi-tensor launch per bucket
         self.inflight = []
+        self.arenas = {}
+
+
+class BufferArena:
+    """The floating-point buffers of a module (BatchNorm running statistics) re-pointed into ONE flat tensor, so that
+    "replica 0's buffers win" (nn.DataParallel semantics) is one in-place broadcast per step — no cat, no copy back.
+    ``num_batches_tracked`` advances by one per training forward on every rank alike: it needs no collective."""
+
+    def __init__(self, module):
+        bufs = [b for b in module.buffers() if b.numel() > 0 and b.is_floating_point()]
+        self.flat = None
+        if not bufs:
+            return
+        n = sum((b.numel() + 3) // 4 * 4 for b in bufs)
+        self.flat = torch.zeros(n, dtype=bufs[0].dtype, device=bufs[0].device)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                k = b.numel()
+                self.flat[off:off + k].copy_(b.reshape(-1))
+                b.data = self.flat[off:off + k].view_as(b)
+                off += (k + 3) // 4 * 4
+
+    def broadcast(self, src=0, group=None):
+        if self.flat is not None:
+            dist.broadcast(self.flat, src=src, group=group)
 
 
 def broadcast_buffers(module, src=0, group=None):
-    """Replica-0 buffers (BatchNorm running stats, num_batches_tracked) win, as under nn.DataParallel."""
+    """Replica-0 buffers (BatchNorm running stats, num_batches_tracked) win, as under nn.DataParallel.  (The wrapper below
+    uses a BufferArena instead; this packed form serves modules whose buffers were not re-pointed.)"""
     bufs = [b for b in module.buffers() if b.numel() > 0]
     if not bufs:
         return
@@ -113,20 +200,27 @@ class RcclDataParallel(nn.Module):
         self.group = group
         self._synced_init = False
         self._buffers_diverged = False   # a training forward has updated this replica's BatchNorm statistics
+        self._buffer_arena = None
+
+    def _broadcast_buffers(self):
+        if self._buffer_arena is None:
+            self._buffer_arena = BufferArena(self.module)
+        self._buffer_arena.broadcast(0, self.group)
 
     def forward(self, *args, **kwargs):
-        if world_size() > 1:
+        if collectives_on():
             if not self._synced_init:
                 broadcast_parameters(self.module, 0, self.group)   # identical replicas (DataParallel re-broadcasts
-                self._synced_init = True                            # every step; replicas never diverge here)
+                broadcast_buffers(self.module, 0, self.group)      # every step; replicas never diverge here)
+                self._synced_init = True
             if self.module.training:
-                broadcast_buffers(self.module, 0, self.group)
+                self._broadcast_buffers()
                 self._buffers_diverged = True
             elif self._buffers_diverged:
                 # first eval forward after a training phase: every replica has since updated its running statistics from
                 # its OWN last batch.  nn.DataParallel evaluates all replicas with device 0's buffers, and the state dict
                 # that gets saved is rank 0's — validate exactly that model on every rank.
-                broadcast_buffers(self.module, 0, self.group)
+                self._broadcast_buffers()
                 self._buffers_diverged = False
             self.module._grad_sync_factory = self._make_bucketer
         else:
@@ -140,8 +234,8 @@ class RcclDataParallel(nn.Module):
 def sync_eval_buffers(net):
     """Called by EVERY rank at the start of a validation phase (also by ranks that will not run a single validation
     batch): replicas whose BatchNorm statistics have drifted during the training phase take rank 0's."""
-    if isinstance(net, RcclDataParallel) and world_size() > 1 and net._buffers_diverged:
-        broadcast_buffers(net.module, 0, net.group)
+    if isinstance(net, RcclDataParallel) and collectives_on() and net._buffers_diverged:
+        net._broadcast_buffers()
         net._buffers_diverged = False
 
 

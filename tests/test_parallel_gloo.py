@@ -111,3 +111,61 @@ def test_eval_after_training_uses_rank0_buffers():
     assert out[0][0] != out[1][0]                       # the replicas did drift apart while training
     assert out[0][1] == out[1][1] == out[0][0]          # ... and validate on rank 0's statistics
     assert out[0][2] == out[1][2]
+
+
+def _arena_job(rank, world):
+    """gradients that are views of one flat arena (FusedAdam's layout: parameter order, 16-byte aligned views) handed over in
+    BACKWARD order: reduced in place, slice by slice, no packed copies"""
+    from microbeseg_amd.parallel import GradBucketer
+    g = torch.Generator().manual_seed(200 + rank)
+    shapes = [(5, 7), (3,), (1000,), (2, 2, 3, 3), (130,), (64, 9)]
+    offs, n = [], 0
+    for sh in shapes:
+        offs.append(n)
+        n += (torch.Size(sh).numel() + 3) // 4 * 4
+    arena = torch.zeros(n)
+    views = []
+    for sh, o in zip(shapes, offs):
+        k = torch.Size(sh).numel()
+        v = arena[o:o + k].view(sh)
+        v.copy_(torch.randn(sh, generator=g))
+        views.append(v)
+    loose = torch.randn(17, generator=g)                    # a gradient outside the arena rides along (packed path)
+    raw = [v.clone() for v in views] + [loose.clone()]
+    b = GradBucketer(bucket_bytes=2048)
+    b.add(views[4:][::-1]); b.add([loose, None]); b.add(views[2:4][::-1]); b.add(views[:2][::-1])
+    n_slices = sum(1 for _, t, _ in b.inflight if t is None)
+    b.finish()
+    return [v.tolist() for v in views] + [loose.tolist()], [t.tolist() for t in raw], n_slices
+
+
+def test_grad_bucketer_reduces_arena_views_in_place():
+    out = _run(_arena_job)
+    avg0, raw0, slices0 = out[0]
+    avg1, raw1, _ = out[1]
+    assert slices0 >= 1                                      # at least one bucket went out as an arena slice before finish()
+    for a0, a1, r0, r1 in zip(avg0, avg1, raw0, raw1):
+        want = (torch.tensor(r0) + torch.tensor(r1)) / 2
+        assert torch.allclose(torch.tensor(a0), want, atol=1e-6)
+        assert torch.allclose(torch.tensor(a1), want, atol=1e-6)
+
+
+def _buffer_arena_job(rank, world):
+    from microbeseg_amd.parallel import BufferArena
+    m = torch.nn.Sequential(torch.nn.BatchNorm2d(4), torch.nn.BatchNorm2d(6))
+    for i, bn in enumerate(m):
+        bn.running_mean.fill_(float(10 * rank + i + 1))
+        bn.running_var.fill_(float(rank + 2))
+    a = BufferArena(m)
+    same = all(b.data_ptr() >= a.flat.data_ptr() and b.data_ptr() < a.flat.data_ptr() + a.flat.numel() * 4
+               for b in m.buffers() if b.is_floating_point())
+    a.broadcast(0)
+    m[0].running_mean += 1.0                                  # the module's buffers ARE the arena
+    return same, m[0].running_mean.tolist(), m[1].running_var.tolist(), float(a.flat[0])
+
+
+def test_buffer_arena_is_one_in_place_broadcast():
+    out = _run(_buffer_arena_job)
+    for r in (0, 1):
+        same, rm, rv, first = out[r]
+        assert same and rm == [2.0] * 4 and rv == [2.0] * 6 and first == 2.0

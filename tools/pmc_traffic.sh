@@ -19,7 +19,8 @@ tag, root = sys.argv[1], sys.argv[2]
 sys.path.insert(0, root)
 sys.argv = ["bench.py"] + sys.argv[3:]
 import bench
-config = bench.workload_key(bench.parse())       # bench.py picks the profile of ITS workload by this record
+config = bench.workload_key(bench.parse())       # bench.py picks the profile of ITS workload by this record ...
+config["csrc_sha"] = bench.csrc_digest()         # ... and of ITS kernel sources (a profile of other sources is stale)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
