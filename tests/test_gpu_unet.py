@@ -62,14 +62,48 @@ def test_net_matches_reference_fixture(name, dev):
     loss.backward()
     floor = grad_floor(fx)
     params = dict(net.named_parameters())
+    # Parameter gradients: 1e-4 against the fp64 evaluation of the same network where fp32 arithmetic itself gets that
+    # close — per tensor max(1e-4, 4 e_ref), e_ref = the REFERENCE's own (torch CPU fp32, the fixture) distance from fp64 —
+    # and never further than 5e-4 from the reference's values.  "Relative" = max |difference| / max |reference| over the
+    # tensor (helpers.rel_err: a max-norm bound, not per element).
+    g64 = _oracle_grads(fx, name, torch.float64)
+    table = []
     for k, v in fx.items():
         if k.startswith("g/"):
-            assert params[k[2:]].grad is not None, k
-            assert rel_err(params[k[2:]].grad.cpu(), v, floor) < 5 * TOL, k
+            pk = k[2:]
+            assert params[pk].grad is not None, k
+            e_ref = rel_err(v, g64[pk], floor)
+            e_hip = rel_err(params[pk].grad.cpu(), g64[pk], floor)
+            table.append((e_hip / max(TOL, 4 * e_ref), pk, e_hip, e_ref))
+            assert e_hip < max(TOL, 4 * e_ref), (k, e_hip, e_ref)
+            assert rel_err(params[pk].grad.cpu(), v, floor) < 5 * TOL, k
+    print("gradient error vs fp64 (ratio to bound, tensor, HIP, reference fp32):")
+    for row in sorted(table, reverse=True)[:5]:
+        print("   %.2f  %-40s %.2e  %.2e" % row)
     sd = net.state_dict()
     for k, v in fx.items():
         if k.startswith("after/"):
             assert np.allclose(sd[k[6:]].cpu().numpy(), v, rtol=1e-4, atol=1e-6), k
+
+
+def _oracle_grads(fx, name, dtype):
+    """parameter gradients of the fixture's training step through oracle/unet_ref.py on the CPU in `dtype`"""
+    from oracle import unet_ref
+    ut, act, norm, filters, ch_out, label_type, pool = variant(name)
+    params = {k: ((v.clone().to(dtype) if v.is_floating_point() else v.clone())) for k, v in state_from(fx).items()}
+    for k, v in params.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    outs = unet_ref.unet_forward(params, torch.from_numpy(fx["x"]).to(dtype), ut, act, norm, filters, pool_method=pool,
+                                 training=True, update_running_stats=True)
+    l1 = torch.from_numpy(fx["label1"])
+    if label_type == "distance":
+        l2 = torch.from_numpy(fx["label2"])
+        loss = unet_ref.regression_loss(outs[0], l1.to(dtype)) + unet_ref.regression_loss(outs[1], l2.to(dtype))
+    else:
+        loss = unet_ref.ce_dice(outs, l1)
+    loss.backward()
+    return {k: v.grad.detach() for k, v in params.items() if getattr(v, "grad", None) is not None}
 
 
 def _oracle_traj(fx, name, make_ref_opt, steps, dtype):
@@ -384,17 +418,16 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
     p16, r16 = oracle(_bf16_rule)
     p32, r32 = oracle(None)
     # Own tolerance of the bf16 mode, stated relative to what bf16 itself does to this network: d_ref = distance of the
-    # bf16 oracle (same operand AND storage rounding points) from the fp32 oracle, relative L2.  The HIP path must be as
-    # close to fp32 as its model (<= 1.25 d_ref), no further from the model than the model is from fp32 (<= 1.25 d_ref: in
-    # these 2-level nets the rounding noise of the two implementations is nearly independent — operands whose last fp32
-    # bits differ round to the other bf16 neighbour, and the materialised mish / elu activation is stored as bf16, which
-    # the oracle does not model; the 5-level net of test_gpu_fullsize.py sits at 0.43 d_ref), and really bf16 (>= 0.4 d_ref).
+    # bf16 oracle (same operand AND storage rounding points, incl. the bf16-stored mish / elu activation) from the fp32
+    # oracle, relative L2.  The HIP path must be as close to fp32 as its model (<= 1.25 d_ref), clearly closer to the model
+    # than the model is to fp32 (<= 0.75 d_ref; measured 0.44-0.58: operands whose last fp32 bits differ between the two
+    # implementations round to the other bf16 neighbour), and really bf16 (>= 0.4 d_ref).
     for o, a, b in zip(outs, r16, r32):
         d_ref = _l2_rel(a.detach(), b.detach())
         d_model, d_fp32 = _l2_rel(o.detach().cpu(), a.detach()), _l2_rel(o.detach().cpu(), b.detach())
         print(f"output: d_ref {d_ref:.2e}, HIP vs bf16 oracle {d_model:.2e}, HIP vs fp32 {d_fp32:.2e}")
         assert 1e-4 < d_ref < 5e-2
-        assert 0.4 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 1.25 * d_ref
+        assert 0.4 * d_ref < d_fp32 < 1.25 * d_ref and d_model < 0.75 * d_ref
     floor = 1e-3 * max(p.grad.abs().max().item() for p in p32.values() if getattr(p, "grad", None) is not None)
     for k, p in net.named_parameters():
         if p32[k].grad.abs().max().item() <= floor:
