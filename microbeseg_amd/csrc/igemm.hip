@@ -25,7 +25,7 @@
 #include "igemm_common.h"
 
 // igemm_p8.hip: one 8-wave workgroup per CU with DMA-streamed weights (>= 128 output channels, bf16 tensors)
-int igemm_p8_try(const MsegIgemm& p, int tw_log2, int tr, int m_fastest, int cus, hipStream_t st, const char** name);
+int igemm_p8_try(const MsegIgemm& p, int tr, int m_fastest, int cus, hipStream_t st);
 
 // identity affine for operands that carry no scale/shift table: lets the K-loop load the tables unconditionally
 __device__ float g_ident_scale[MSEG_MAX_CH];
@@ -2792,7 +2792,7 @@ static int igemm_dispatch(const MsegIgemm* pp, void* stream) {
       if (tr == 0) MSEG_HALO512(0); else if (tr == 1) MSEG_HALO512(1); else MSEG_HALO512(2);
 #undef MSEG_HALO512
     } else if (p.precision == MSEG_PREC_BF16 && wide && s16 && ks == 1 &&
-               (p8rc = igemm_p8_try(q, tw_log2, tr, m_fastest, c64p_workgroups(), st, nullptr)) != 0) {
+               (p8rc = igemm_p8_try(q, tr, m_fastest, c64p_workgroups(), st)) != 0) {
       // >= 128 output channels on bf16 tensors with at least one 256-pixel tile per CU: igemm_p8.hip
       if (p8rc < 0) return p8rc;
     } else if (p.precision == MSEG_PREC_BF16 && wide && s16 && g_w4m_on && ks == 1 && tw_log2 >= 3 &&

@@ -24,6 +24,13 @@ typedef __bf16 p8_bf16x8 __attribute__((ext_vector_type(8)));
 
 #define P8_AROW 80              // bytes between halo rows in LDS (64 of data + 16: rows distinct mod 16 never share a bank)
 
+// pixel tile of a launch: TH x TW pixels, TW a divisor of the image width.  32- and 16-pixel-wide tiles fill the BM GEMM rows
+// exactly; images whose width is no multiple of 16 (the 40- and 20-pixel-wide deep levels of 320 x 320 crops) take tiles as
+// wide as the image and floor(BM / W) rows tall (240 of 256 GEMM rows live).  HP: LDS rows between two halo lines — 32 for
+// 16-pixel tiles (the 16 rows a ds_read_b128 lane group touches then stay distinct modulo 16), TW + 2 otherwise (conflict-
+// free for 32-pixel tiles; image-wide tiles pay a 2-way conflict on the lanes next to a line wrap).
+struct P8Tile { int TW, TH, HP; };
+
 template <int BM_, int BN_>
 struct P8Cfg {
   static constexpr int BM = BM_, BN = BN_;
@@ -35,7 +42,7 @@ struct P8Cfg {
   static constexpr int HREAL = BM == 256 ? 340 : 612;
   static constexpr int HL = (HREAL + 127) / 128;        // 16-byte halo loads per thread and chunk
   // LDS rows of a halo buffer: 16-wide tiles use a line pitch of 32 rows
-  static constexpr int HROWS_LDS = BM == 256 ? 17 * 32 + 18 : 17 * 34 + 34;
+  static constexpr int HROWS_LDS = BM == 256 ? 17 * 32 + 18 : 17 * 34 + 34;     // 562 / 612 (image-wide tiles: <= 8 x 66 + slack)
   static constexpr int HALO_BYTES = HROWS_LDS * P8_AROW;
   static constexpr int SLOT_BYTES = BN * 64;
   static constexpr int TAB_BYTES = 256;                  // norm-on-load tables of one chunk: scale[32] | shift[32]
@@ -67,7 +74,7 @@ __device__ __forceinline__ void p8_issue_w(const void* w, unsigned wbytes, char*
 // destinations split at a multiple of 64 channels, optional accumulation into the destination, bf16 or fp32 tensors.
 template <typename Cfg>
 __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int cw /* first channel of this wave */, int wm,
-                                            int lane, int tw_log2, int img, int oy0, int ox0) {
+                                            int lane, int TW, int TH, int img, int oy0, int ox0) {
   const int li = lane & 31, lh = lane >> 5;
   const MsegIgemm* pe = (const MsegIgemm*)__builtin_amdgcn_kernarg_segment_ptr();  // kernel argument 0 (kept out of the
   asm volatile("" : "+s"(pe));                                                     // K-loop's SGPRs, like igemm_epilogue)
@@ -81,7 +88,6 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
   const int ld = second ? pe->ld1 : pe->ld0;
   const int accf = second ? pe->acc1 : pe->acc0;
   const int noff = cw - (second ? e_split : 0);
-  const int TWm = (1 << tw_log2) - 1;
 #pragma unroll
   for (int b = 0; b < Cfg::NB; ++b) {
     float4 bq[4];
@@ -97,8 +103,9 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
 #pragma unroll
     for (int a = 0; a < Cfg::MB; ++a) {
       const int i = wm * Cfg::TM + a * 32 + li;
-      const int oy = oy0 + (i >> tw_log2), ox = ox0 + (i & TWm);
-      const bool ok = oy < e_H;                        // tile rows below the image
+      const int iy = i / TW;
+      const int oy = oy0 + iy, ox = ox0 + (i - iy * TW);
+      const bool ok = (iy < TH) & (oy < e_H);          // dead GEMM rows of a tile, tile rows below the image
       const size_t e0 = ((size_t)(img * e_H + oy) * e_W + ox) * ld + noff + b * 32;   // element offset of channel quad 0
       float v[16];
 #pragma unroll
@@ -142,7 +149,7 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
 }
 
 template <int BM, int BN, int TR>
-__global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, int tw_log2, int m_fastest, int ntiles, int dbg) {
+__global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, const P8Tile tg, int m_fastest, int ntiles, int dbg) {
   using Cfg = P8Cfg<BM, BN>;
   constexpr int HL = Cfg::HL, NP = Cfg::NP, RING = Cfg::RING, P = Cfg::P;
   constexpr int CSTAGES = 7 - P;                       // stages P .. 6 of a chunk commit the next chunk's halo rows
@@ -157,11 +164,11 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, int
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int li = lane & 31, lh = lane >> 5;
   const int srow = tid >> 2, scol = tid & 3;           // halo staging: 128 rows x 4 groups of 8 channels per pass
-  const int TW = 1 << tw_log2, TH = BM >> tw_log2, HW2 = TW + 2;
-  const int HP = tw_log2 == 5 ? 34 : 32;               // LDS rows between two halo lines
+  const int TW = tg.TW, TH = tg.TH, HW2 = TW + 2;       // tile = TH x TW pixels (TH * TW <= BM; the rest are dead GEMM rows)
+  const int HP = tg.HP;                                // LDS rows between two halo lines
   const int NREAL = (TH + 2) * HW2;
   const int H = p.Hi, W = p.Wi;
-  const int tiles_x = W >> tw_log2, tiles_y = (H + TH - 1) / TH;
+  const int tiles_x = W / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles_n = (p.Ngemm + BN - 1) / BN;
   const int ntiles_m = ntiles / ntiles_n;
   const bool conv = p.mode == MSEG_MODE_CONV;
@@ -187,8 +194,9 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, int
   int abase[Cfg::MB];
 #pragma unroll
   for (int a = 0; a < Cfg::MB; ++a) {
-    const int i = wm * Cfg::TM + a * 32 + li;
-    abase[a] = ((i >> tw_log2) * HP + (i & (TW - 1))) * P8_AROW + lh * 16;
+    const int i = wm * Cfg::TM + a * 32 + li;          // GEMM row -> pixel (i / TW, i % TW) of the tile; rows >= TH * TW are
+    const int iy = i / TW;                             // dead (their reads land in the halo buffer's slack, their results
+    abase[a] = (iy * HP + (i - iy * TW)) * P8_AROW + lh * 16;   // are never stored)
   }
   int bbase[2][2];
 #pragma unroll
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, int
     if (dbg & 1) {                                       // timing ablation: no stores (one element keeps the MFMAs alive)
       if (acc[0][0][0] == 12345.678f) p.dst0[0] = acc[1][1][3];
     } else {
-      p8_epilogue<Cfg>(acc, c_n0 + wn * 64, wm, lane, tw_log2, c_img, c_oy0, c_ox0);
+      p8_epilogue<Cfg>(acc, c_n0 + wn * 64, wm, lane, TW, TH, c_img, c_oy0, c_ox0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, int
 }
 
 #ifdef P8_INSPECT       // device-only build of one instantiation for reading the assembly
-template __global__ void igemm_p8_kernel<P8_INSPECT>(const MsegIgemm, int, int, int, int);
+template __global__ void igemm_p8_kernel<P8_INSPECT>(const MsegIgemm, const P8Tile, int, int, int);
 #else
 // Launches the kernel above when the layer qualifies; returns 1 if it did, 0 if the caller has to pick another kernel,
 // a negative MSEG_E* code on a launch error.  `tr`: 0 plain operand, 1 ReLU / no activation + affine, 2 any activation.
@@ -478,54 +486,59 @@ extern "C" int mseg_igemm_set_p8(int on) {
   return MSEG_OK;
 }
 
-static long long p8_tiles(const MsegIgemm& p, int tw_log2, int BMv) {
-  const int TH = BMv >> tw_log2;
-  const long long rows = (long long)((p.Hi + TH - 1) / TH) * TH;
-  if ((long long)p.Hi * 5 < rows * 4) return 0;        // more than a fifth of the tile rows below the image
-  return (long long)p.NB * ((p.Hi + TH - 1) / TH) * (p.Wi >> tw_log2);
+// tile geometry for this layer and BM, or false (tiles that would waste more than ~30 % of their GEMM rows, images narrower
+// than 16 pixels, ...); *tiles = pixel tiles of the launch
+static bool p8_geometry(const MsegIgemm& p, int BMv, P8Tile* tg, long long* tiles) {
+  const int W = p.Wi, H = p.Hi;
+  if ((W % 32) == 0) { tg->TW = 32; tg->HP = 34; }
+  else if ((W % 16) == 0 && BMv == 256) { tg->TW = 16; tg->HP = 32; }
+  else if (BMv == 256 && W >= 16 && W <= 64 && (W % 4) == 0) { tg->TW = W; tg->HP = W + 2; }
+  else return false;
+  tg->TH = BMv / tg->TW;
+  if ((tg->TH + 2) * (tg->TW + 2) > (BMv == 256 ? 340 : 612)) return false;      // staging loads per thread (P8Cfg::HREAL)
+  if ((tg->TH + 1) * tg->HP + tg->TW + 2 > (BMv == 256 ? 562 : 612)) return false;   // LDS rows of a halo buffer
+  const long long ty = (H + tg->TH - 1) / tg->TH;
+  // live GEMM rows / rows computed: dead rows of a tile and tile rows below the image
+  if ((long long)H * W * 10 < ty * (W / tg->TW) * BMv * 7) return false;
+  *tiles = (long long)p.NB * ty * (W / tg->TW);
+  return true;
 }
 
-int igemm_p8_try(const MsegIgemm& p, int tw_log2, int tr, int m_fastest, int cus, hipStream_t st, const char** name) {
+int igemm_p8_try(const MsegIgemm& p, int tr, int m_fastest, int cus, hipStream_t st) {
   if (g_p8_on < 0) {
     const char* e = getenv("MSEG_P8");                  // ablation from the shell: MSEG_P8=0 python bench.py ...
     g_p8_on = e ? atoi(e) : 1;
   }
   if (!(g_p8_on & 255)) return 0;
-  if (tw_log2 > 5 || tw_log2 < 4) return 0;
   if (p.Ngemm < 128 || (p.Ngemm % 64) != 0 || (p.Cin % KC) != 0) return 0;
   if (p.split < p.Ngemm && (p.split % 64) != 0) return 0;            // a wave's 64 channels go to ONE destination
   if ((p.ld0 % 8) != 0 || (p.split < p.Ngemm && (p.ld1 % 8) != 0)) return 0;   // 16-byte stores
   if (((uintptr_t)p.dst0 | (uintptr_t)p.dst1) & 15) return 0;
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
   if (p.nsrc > 1 && (p.src[0].C % KC) != 0) return 0;
+  if ((long long)p.Hi * p.Wi < 256) return 0;
 #define P8_LAUNCH(BM_, BN_, tiles_)                                                                                    \
   do {                                                                                                                 \
     const long long nt_ = (tiles_) * ((p.Ngemm + BN_ - 1) / BN_);                                                      \
     const dim3 grid((unsigned)(nt_ < cus ? nt_ : cus));                                                                \
-    if (tr == 0) MSEG_KL((igemm_p8_kernel<BM_, BN_, 0>), grid, dim3(512), 0, st, p, tw_log2, m_fastest, (int)nt_, g_p8_on >> 8);    \
-    else if (tr == 1) MSEG_KL((igemm_p8_kernel<BM_, BN_, 1>), grid, dim3(512), 0, st, p, tw_log2, m_fastest, (int)nt_, g_p8_on >> 8); \
-    else MSEG_KL((igemm_p8_kernel<BM_, BN_, 2>), grid, dim3(512), 0, st, p, tw_log2, m_fastest, (int)nt_, g_p8_on >> 8);            \
+    if (tr == 0) MSEG_KL((igemm_p8_kernel<BM_, BN_, 0>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);    \
+    else if (tr == 1) MSEG_KL((igemm_p8_kernel<BM_, BN_, 1>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8); \
+    else MSEG_KL((igemm_p8_kernel<BM_, BN_, 2>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);            \
     MSEG_LAUNCH_CHECK();                                                                                               \
   } while (0)
+  P8Tile tg;
+  long long t = 0;
   if (p.Ngemm % 256 == 0) {
-    const long long t = p8_tiles(p, tw_log2, 256);
-    if (t * (p.Ngemm / 256) < cus) return 0;
+    if (!p8_geometry(p, 256, &tg, &t) || t * (p.Ngemm / 256) < cus) return 0;
     P8_LAUNCH(256, 256, t);
-    if (name) *name = "igemm_p8_kernel<256, 256>";
     return 1;
   }
-  if ((g_p8_on & 255) != 2 && tw_log2 == 5) {
-    const long long t = p8_tiles(p, tw_log2, 512);
-    if (t * ((p.Ngemm + 127) / 128) >= cus) {
-      P8_LAUNCH(512, 128, t);
-      if (name) *name = "igemm_p8_kernel<512, 128>";
-      return 1;
-    }
+  if ((g_p8_on & 255) != 2 && p8_geometry(p, 512, &tg, &t) && t * ((p.Ngemm + 127) / 128) >= cus) {
+    P8_LAUNCH(512, 128, t);
+    return 1;
   }
-  const long long t = p8_tiles(p, tw_log2, 256);
-  if (t * ((p.Ngemm + 127) / 128) < cus) return 0;
+  if (!p8_geometry(p, 256, &tg, &t) || t * ((p.Ngemm + 127) / 128) < cus) return 0;
   P8_LAUNCH(256, 128, t);
-  if (name) *name = "igemm_p8_kernel<256, 128>";
   return 1;
 #undef P8_LAUNCH
 }

@@ -1081,7 +1081,10 @@ def test_bf16_storage_256_pixel_tiles(eng, N, Cin, Cout, H, W, act, per_sample, 
     (20, 256, 256, 80, 80, "relu", True, True, "igemm_p8_kernel<256, 256, 1>"),       # 16-wide tiles, per-sample tables, concat
     (32, 128, 256, 72, 64, "mish", False, False, "igemm_p8_kernel<256, 256, 2>"),     # tile rows below the image (72 = 9 x 8)
     (40, 64, 128, 48, 48, "none", False, False, "igemm_p8_kernel<256, 128, 0>"),      # plain operand, 256 x 128 tiles
-    (36, 512, 1024, 32, 32, "elu", False, False, "igemm_p8_kernel<256, 256, 2>")])    # four 256-channel tiles per pixel tile
+    (36, 512, 1024, 32, 32, "elu", False, False, "igemm_p8_kernel<256, 256, 2>"),     # four 256-channel tiles per pixel tile
+    (40, 256, 512, 40, 40, "relu", False, True, "igemm_p8_kernel<256, 256, 1>"),      # image-wide tiles 40 x 6 (240 live rows)
+    (80, 512, 1024, 20, 20, "mish", True, False, "igemm_p8_kernel<256, 256, 2>"),     # image-wide tiles 20 x 12
+    (64, 128, 256, 44, 44, "none", False, False, "igemm_p8_kernel<256, 256, 0>")])    # 44 x 5 (220 live rows), 9 tile rows
 def test_bf16_storage_p8_kernel(eng, N, Cin, Cout, H, W, act, per_sample, two_src, want):
     """Layers with >= 128 output channels on bf16 tensors and at least one tile per CU take the one-workgroup-per-CU kernel
     with DMA-streamed weights (igemm_p8.hip): persistent tile walk (more tiles than CUs, a ragged last round), transposed

@@ -54,6 +54,10 @@ def check():
         (40, 48, 48, (64,), 128, "relu", False, True),         # TW 16, BN 128, 256-pixel tiles
         (64, 40, 32, (512,), 512, "elu", False, True),         # TW 32, 40 rows = 5 x 8
         (32, 32, 32, (512,), 1024, "relu", False, True),
+        (32, 40, 40, (512,), 512, "relu", False, True),        # image-wide tiles: 40 x 6 pixels (240 of 256 GEMM rows live)
+        (32, 20, 20, (512, 512), 1024, "relu", True, True),    # 20 x 12 pixels, two sources, per-sample tables
+        (64, 44, 44, (128,), 256, "mish", False, True),        # 44 x 5 pixels
+        (48, 52, 24, (256,), 256, "none", False, False),       # 24 x 10 pixels, plain operand
     ]
     for (N, H, W, cins, cout, act, ps, aff) in cases:
         cin = sum(cins)
