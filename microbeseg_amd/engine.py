@@ -10,6 +10,7 @@ their autograd backward (train.py:488).  Python only sequences kernels; every FL
   ``torch.autograd.Function`` so that ``loss.backward()`` and the stock optimizers keep working (plumbing only).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -892,12 +893,58 @@ def _grad_buf(param, direct):
     return torch.empty_like(param)
 
 
+_wgrad_overlap = os.environ.get("MSEG_WGRAD_OVERLAP", "1") != "0"
+_side_streams = {}
+
+
+def set_wgrad_overlap(flag):
+    """Weight gradients on a second HIP stream (default on; MSEG_WGRAD_OVERLAP=0 in the environment turns it off)."""
+    global _wgrad_overlap
+    _wgrad_overlap = bool(flag)
+
+
+def _wgrad_side_stream(dev):
+    s = _side_streams.get(dev)
+    if s is None:
+        # lowest priority: the data-gradient chain on the main stream gets the CUs first, the weight gradients fill in
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=0)
+    return s
+
+
 def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
-    """grad_outs: list of NCHW gradients (None allowed) matching the forward outputs.  Returns {id(param): grad}."""
+    """grad_outs: list of NCHW gradients (None allowed) matching the forward outputs.  Returns {id(param): grad}.
+
+    The weight gradient of a layer depends on that layer's dz only and feeds nothing but the optimizer, while the chain
+    dz -> data gradient -> next layer's normalisation backward is what the rest of the pass waits for.  The weight-gradient
+    kernels (matrix-core bound) therefore run on a SECOND stream, behind an event on the dz they read: they fill the
+    partial last rounds of the persistent data-gradient kernels and run under the HBM-bound normalisation passes of the
+    layers that follow; the streams join at the end of the pass.  Same kernels, same arguments, same results.  Not used
+    while a hipGraph is being captured or when gradients are handed to a data-parallel bucketer as they are produced."""
     lib = _lib.load()
     grads = {}
     if direct is None:
         direct = set()
+    dev = tape.nodes[0].z.device
+    side = None
+    # (bf16 mode only: there the step has long HBM-bound stretches next to short matrix kernels; the fp32 step is matrix-core
+    # bound almost everywhere and measured 0.8 % slower with the second stream)
+    if _wgrad_overlap and _precision == "bf16" and on_grads is None and dev.type == "cuda" and \
+            not torch.cuda.is_current_stream_capturing():
+        side = _wgrad_side_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                           # nothing of this pass runs ahead of what is already queued
+
+    def on_side(dz, fn):
+        """run the launches of `fn` on the side stream once everything queued so far (dz included) is done"""
+        if side is None:
+            return fn(ws)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            fn(_SideWs(ws))
+        dz.record_stream(side)                           # dz is freed on the main stream while the side stream may still read it
+
     # heads
     for (head, node), go in zip(tape.heads, grad_outs):
         hc = head.conv
@@ -952,7 +999,8 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
         if sp.kind == "up":
             cin, cout = wt.shape[0], wt.shape[1]
             # dW[ci][co][a][b] = sum x[p][ci] * dz[2p+(a,b)][co]
-            wgrad(i0.src(), [plain_src(dz, cout)], dW, N, i0.H, i0.W, node.H, node.W, 2, 2, 2, 0, ws)
+            on_side(dz, lambda w_, i0=i0, dz=dz, dW=dW, cout=cout, node=node: wgrad(
+                i0.src(), [plain_src(dz, cout)], dW, N, i0.H, i0.W, node.H, node.W, 2, 2, 2, 0, w_))
             # dx[p][ci] = sum_{ab,co} dz[2p+(a,b)][co] * W[ci][co][a][b]
             wp = pack_weight(conv.weight, 4, cin, cout, 1, cout * 4, 4, kind="dgrad")
             tgt, acc = _accumulate_target(i0, None)
@@ -967,8 +1015,9 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
                 check(lib.mseg_first_wgrad(i0.z.data_ptr(), dz.data_ptr(), _st(dz), N, node.H, node.W, cout, dW.data_ptr(),
                                            w1.data_ptr(), _stream()), "first_wgrad")
             else:
-                wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H, i0.W, 3, 3, stride,
-                      1, ws, nch_store=cin if is_first else None)
+                on_side(dz, lambda w_, dz=dz, ins=ins, dW=dW, cout=cout, node=node, i0=i0, stride=stride, cin=cin,
+                        is_first=is_first: wgrad(plain_src(dz, cout), [n.src() for n in ins], dW, N, node.H, node.W, i0.H,
+                                                 i0.W, 3, 3, stride, 1, w_, nch_store=cin if is_first else None))
             if not is_first:
                 wp = pack_weight(conv.weight, 9, cin, cout, 1, 9, cin * 9, kind="dgrad")
                 morder = MORDER_PARITY if stride == 2 else MORDER_LINEAR
@@ -987,7 +1036,19 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
         if on_grads is not None:        # data-parallel: gradients of this layer are final -> start their all-reduce
             on_grads([dW, dbias, dgamma, dbeta])
         del dz, gy
+    if side is not None:
+        main.wait_stream(side)                           # the optimizer (and whoever reads .grad) sees finished weight gradients
     return grads
+
+
+class _SideWs:
+    """the side stream's own scratch names inside the module's Workspace: buffers allocated and used on that stream only"""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def get(self, name, nbytes, zero=False):
+        return self.ws.get(name + "@side", nbytes, zero)
 
 
 # ---- autograd glue -------------------------------------------------------------------------------------------
