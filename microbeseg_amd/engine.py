@@ -903,6 +903,10 @@ def set_wgrad_overlap(flag):
     _wgrad_overlap = bool(flag)
 
 
+def get_wgrad_overlap():
+    return _wgrad_overlap
+
+
 def _wgrad_side_stream(dev):
     s = _side_streams.get(dev)
     if s is None:

@@ -61,6 +61,10 @@ class InferWorker(QObject):
     precision = "fp32"
     # [extension] edge length of the tiles of sliding-window inference (``sliding_window=True``; inference/tiling.py)
     tile_size = 2048
+    # [measurement hook, None in production] callable(prediction) -> prediction, applied to the network's output before the
+    # post-processing.  bench.py uses it to hand the watershed realistic distance maps: an UNTRAINED network (there are no
+    # checkpoints offline) predicts one confluent blob, whose flood is a single sequential component.
+    prediction_hook = None
 
     def __init__(self, img_id_list=None, inference_path=None, omero_username=None, omero_password=None, omero_host=None,
                  omero_port=None, group_id=None,
@@ -188,6 +192,8 @@ class InferWorker(QObject):
             self.progress.emit(int(100 * (f + 1) / len(img)))
 
         def launch_postproc(frame, pred, pads):
+            if self.prediction_hook is not None:
+                pred = self.prediction_hook(pred)
             border, cell = pred
             cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
             border = border[0, 0, pads[0]:, pads[1]:].contiguous()
