@@ -27,8 +27,8 @@ typedef __bf16 p8_bf16x8 __attribute__((ext_vector_type(8)));
 // pixel tile of a launch: TH x TW pixels, TW a divisor of the image width.  32- and 16-pixel-wide tiles fill the BM GEMM rows
 // exactly; images whose width is no multiple of 16 (the 40- and 20-pixel-wide deep levels of 320 x 320 crops) take tiles as
 // wide as the image and floor(BM / W) rows tall (240 of 256 GEMM rows live).  HP: LDS rows between two halo lines — 32 for
-// 16-pixel tiles (the 16 rows a ds_read_b128 lane group touches then stay distinct modulo 16), TW + 2 otherwise (conflict-
-// free for 32-pixel tiles; image-wide tiles pay a 2-way conflict on the lanes next to a line wrap).
+// 16-pixel tiles and TW + 16 for image-wide ones (a line wrap inside a 32-pixel MFMA block then moves on by a multiple of
+// 16 rows: the 16 rows a ds_read_b128 lane group touches stay distinct modulo 16), TW + 2 for 32-pixel tiles (no wrap).
 struct P8Tile { int TW, TH, HP; };
 
 template <int BM_, int BN_>
@@ -492,7 +492,7 @@ static bool p8_geometry(const MsegIgemm& p, int BMv, P8Tile* tg, long long* tile
   const int W = p.Wi, H = p.Hi;
   if ((W % 32) == 0) { tg->TW = 32; tg->HP = 34; }
   else if ((W % 16) == 0 && BMv == 256) { tg->TW = 16; tg->HP = 32; }
-  else if (BMv == 256 && W >= 16 && W <= 64 && (W % 4) == 0) { tg->TW = W; tg->HP = W + 2; }
+  else if (BMv == 256 && W >= 16 && W <= 64 && (W % 4) == 0) { tg->TW = W; tg->HP = W + 16; }   // line wrap = 16 rows further
   else return false;
   tg->TH = BMv / tg->TW;
   if ((tg->TH + 2) * (tg->TW + 2) > (BMv == 256 ? 340 : 612)) return false;      // staging loads per thread (P8Cfg::HREAL)
