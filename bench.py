@@ -511,7 +511,8 @@ def train_metric(args, dev, world, rank, timing=True):
     dt_bracketed = None
     if two_pass:
         engine.set_kernel_timer(prof)
-        overlap = engine.get_wgrad_overlap()
+        overlap, dec_overlap = engine.get_wgrad_overlap(), engine.get_decoder_overlap()
+        engine.set_decoder_overlap(False)
         engine.set_wgrad_overlap(False)      # one kernel at a time under the brackets: an event pair around a launch that
         fence()                              # shares the chip with another stream's kernel would time both
         t0 = time.perf_counter()
@@ -521,6 +522,7 @@ def train_metric(args, dev, world, rank, timing=True):
         dt_bracketed = time.perf_counter() - t0
         engine.set_kernel_timer(None)
         engine.set_wgrad_overlap(overlap)
+        engine.set_decoder_overlap(dec_overlap)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
