@@ -454,10 +454,8 @@ def train_metric(args, dev, world, rank, timing=True):
     net = build_unet(args.arch, args.act, "conv", args.norm, dev, world if world > 1 else 1,
                      ch_out=3 if args.arch == "U" else 1, filters=filters)
     graph = args.graph
-    if graph:
-        if world > 1 or args.optimizer != "adam":
-            raise SystemExit("--graph: single GPU and Adam only")
-        timing = False
+    if graph and (world > 1 or args.optimizer != "adam"):
+        raise SystemExit("--graph: single GPU and Adam only")
     if args.optimizer == "adam":
         from microbeseg_amd.training.optim import make_adam
         opt = make_adam(net.parameters(), capturable=graph)
@@ -480,6 +478,7 @@ def train_metric(args, dev, world, rank, timing=True):
         return loss
 
     warmup = args.warmup
+    eager_step = one_step
     if graph:
         from microbeseg_amd.training.graph_step import GraphedTrainStep
         one_step = GraphedTrainStep(one_step, opt, warmup=2)
@@ -505,6 +504,7 @@ def train_metric(args, dev, world, rank, timing=True):
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_host = time.perf_counter() - t0        # the host's share: all K steps enqueued (it may have waited for queue space)
     fence()
     dt = time.perf_counter() - t0
     engine.set_kernel_timer(None)
@@ -517,7 +517,7 @@ def train_metric(args, dev, world, rank, timing=True):
         fence()                              # shares the chip with another stream's kernel would time both
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i)
+            eager_step(*batches[i % len(batches)])       # (a replayed graph has no launches to bracket)
         fence()
         dt_bracketed = time.perf_counter() - t0
         engine.set_kernel_timer(None)
@@ -551,6 +551,7 @@ def train_metric(args, dev, world, rank, timing=True):
         "config": {"workload": wl, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if graph else "eager"},
         "per_gpu_value": round(value / world, 3),
+        "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
     }
     if world > 1:
         out["config"]["collective"] = "RCCL all-reduce of fp32 gradient buckets, overlapped with the backward"
@@ -663,8 +664,10 @@ def main():
         out["secondary"] = {}
         for tag, kw in (("unet_ce_dice_bf16_256", dict(arch="U", precision="bf16")),
                         ("groupnorm_bf16_320", dict(norm="gn", precision="bf16", size=320)),
-                        ("batch4_fp32_256", dict(batch=4)),
-                        ("batch4_bf16_256", dict(batch=4, precision="bf16"))):
+                        ("batch4_fp32_256", dict(batch=4, graph=True, steps=20)),
+                        ("batch4_bf16_256", dict(batch=4, precision="bf16", graph=True, steps=20))):
+            # (batch 4, the GUI / CLI default: ~600 launches of a few us each — the step is replayed from a hipGraph, as
+            # TrainWorker does on one GPU with Adam; see training/graph_step.py)
             a3 = copy.copy(args)
             a3.graph = False
             a3.steps, a3.warmup = 6, 3

@@ -94,6 +94,16 @@ typedef struct MsegIgemm {
    * launch simply is not split.  Size: mseg_igemm_workspace_bytes(). */
   void* ws;
   size_t ws_bytes;
+  /* optional: statistics of the output for the normalisation that follows it, taken in the epilogue instead of by a pass
+   * over the stored tensor (unets.py:127-134: conv -> act -> norm).  stats != NULL asks for per-tile partial sums
+   * stats[row][0 / 1][Ngemm] = sum / sum of squares of act(z) over the pixels of partial row `row`, z as stored (i.e. of the
+   * bf16-rounded value for a bf16 destination), act = stats_act (MSEG_ACT_NONE or MSEG_ACT_RELU).  Only some kernels can:
+   * mseg_igemm_query() on the same descriptor reports in MsegKernelInfo.stats_rows how many rows the call will write
+   * (0: none — the buffer is left untouched and the caller runs mseg_norm_stats); size the buffer for that.  Plain epilogue,
+   * one destination, no accumulation.  Reduced by mseg_norm_stats_from_conv().                                           */
+  float* stats;
+  int32_t stats_act;
+  int32_t reserved0;
 } MsegIgemm;
 
 int mseg_igemm(const MsegIgemm* p, void* stream);
@@ -108,6 +118,8 @@ typedef struct MsegKernelInfo {
   int32_t launches;  /* kernel launches of the call (split-K partial + reduction = 2; one-off table initialisation counted) */
   uint32_t grid, block;
   size_t workspace;  /* split-K scratch bytes the call uses (0: none) */
+  int32_t stats_rows; /* partial rows the call writes to MsegIgemm.stats (0: the kernel takes no statistics) */
+  int32_t reserved0;
 } MsegKernelInfo;
 int mseg_igemm_query(const MsegIgemm* p, MsegKernelInfo* info);
 /* name of the main kernel of this thread's last mseg_igemm / mseg_wgrad call ("" before the first) */
@@ -209,13 +221,22 @@ int mseg_pack_weights_multi(const MsegPackJob* jobs_dev, int njobs, unsigned tot
  * reductions (the last workgroups of a pass finish the sums and write the tables: no separate reduction launches):
  * ZERO them once after allocating ws (hipMemset); every call leaves them zero.  One ws per concurrent stream.          */
 size_t mseg_norm_workspace_bytes(int N, int HW, int C);
-/* Test / ablation hook: 0 = a pass is followed by separate reduction / finalize launches again (same results). Default 1. */
+/* 1 = the last workgroups of a pass finish the reductions inside the pass kernel, 0 = a pass is followed by separate
+ * reduction / finalize launches (same results, bit for bit).  Default 0 (measured faster at batch 32); MSEG_NORM_TAILS in
+ * the environment sets it for a process. */
 int mseg_norm_set_tails(int on);
 /* st: MSEG_ST_F32 / MSEG_ST_BF16 = storage of the activation tensors of the call (z, act_out; gy, dz, act_in below).  With
  * bf16 storage a thread owns 8 channels (C % 8 == 0) and the statistics are those of the values as stored.           */
 int mseg_norm_stats(const void* z, int N, int HW, int C, int st, int act, int norm, const float* gamma,
                     const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
                     float* running_mean, float* running_var, float momentum, void* act_out, void* ws, void* stream);
+/* BatchNorm statistics from the partial sums a convolution's epilogue left (MsegIgemm.stats: part[rows][2][C], C = the
+ * launch's Ngemm): the same tables, running statistics and saved mean / rstd as mseg_norm_stats(norm = MSEG_NORM_BN) on the
+ * stored tensor, without reading it.  count = N * H * W values per channel.  Fixed summation order (rows in 16 slices, then
+ * the slices).  ws: as for mseg_norm_stats.                                                                             */
+int mseg_norm_stats_from_conv(const float* part, int rows, int C, long long count, const float* gamma, const float* beta,
+                              float eps, float* scale, float* shift, float* mean, float* rstd, float* running_mean,
+                              float* running_var, float momentum, void* ws, void* stream);
 /* act_out (nullable): also store a = act(z).  Used for the expensive activations (mish / elu / leakyrelu): consumers then
  * read `a` with MSEG_ACT_NONE instead of re-evaluating the activation for each of the 9 taps in their K-loops.
  * mseg_activation: a = act(z) alone (eval-mode BatchNorm has no statistics pass).                              */
@@ -289,6 +310,13 @@ int mseg_polygons_trace(const uint16_t* labels, int H, int W, const int32_t* sta
  * the bias corrections and lr / bc1 are evaluated in fp64 and rounded to fp32 once, as torch does.                   */
 int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n, double lr,
                            double beta1, double beta2, double eps, int step, void* stream);
+/* The same update with learning rate and step count in DEVICE memory (no per-step host scalar: the launch can be recorded
+ * in a hipGraph and replayed).  `state` = 4 doubles on the device: [0] learning rate (the host rewrites it when a scheduler
+ * changes it), [1] steps done so far (this call adds 1 before it updates), [2..3] scratch of the call.  Two launches: a
+ * one-thread kernel that advances the counter and derives lr / (1 - beta1^step), sqrt(1 - beta2^step) in fp64, and the
+ * update.                                                                                                               */
+int mseg_adam_amsgrad_step_dev(float* p, const float* g, float* m, float* v, float* vmax, size_t n, double* state,
+                               double beta1, double beta2, double eps, void* stream);
 /* One Ranger update of one parameter tensor (ranger2020.py:142-206): gradient centralisation over dims 1.. (do_gc, rows =
  * shape[0]), moments, rectified or plain-momentum update with step_lr = step_size * lr (host-side RAdam buffer,
  * ranger2020.py:160-176), and the lookahead blend every k-th step (lookahead = 1).                              */

@@ -36,7 +36,8 @@ class MsegIgemm(C.Structure):
                 ("mode", C.c_int32), ("morder", C.c_int32),
                 ("Ngemm", C.c_int32), ("epi", C.c_int32), ("split", C.c_int32), ("ld0", C.c_int32),
                 ("ld1", C.c_int32), ("acc0", C.c_int32), ("acc1", C.c_int32), ("Cq", C.c_int32),
-                ("precision", C.c_int32), ("dst_dtype", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("precision", C.c_int32), ("dst_dtype", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("stats", C.c_void_p), ("stats_act", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MsegWgrad(C.Structure):
@@ -49,7 +50,7 @@ class MsegWgrad(C.Structure):
 
 class MsegKernelInfo(C.Structure):
     _fields_ = [("name", C.c_char * 120), ("precision", C.c_int32), ("launches", C.c_int32), ("grid", C.c_uint32),
-                ("block", C.c_uint32), ("workspace", C.c_size_t)]
+                ("block", C.c_uint32), ("workspace", C.c_size_t), ("stats_rows", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MsegPackJob(C.Structure):
@@ -95,6 +96,7 @@ SIGNATURES = {
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_norm_set_tails": (_I, [_I]),
+    "mseg_norm_stats_from_conv": (_I, [_P, _I, _I, C.c_longlong, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mseg_activation": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mseg_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "mseg_ce_dice_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "mseg_ce_dice_bwd": (_I, [_P, _P, _I, _I, _I, _P, C.c_double, C.c_double, _P, _P, _P]),
     "mseg_adam_amsgrad_step": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _D, _D, _D, _I, _P]),
+    "mseg_adam_amsgrad_step_dev": (_I, [_P, _P, _P, _P, _P, _SZ, _P, _D, _D, _D, _P]),
     "mseg_ranger_step": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _D, _D, _D, _D, _I, _I, _I, _D, _P]),
     "mseg_ranger_step_multi": (_I, [_P, _I, _D, _D, _D, _D, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),

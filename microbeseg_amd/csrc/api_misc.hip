@@ -37,6 +37,7 @@ extern "C" void mseg_dispatch_note(int precision, size_t workspace) {
   g_call.precision = precision;
   g_call.workspace = workspace;
 }
+extern "C" void mseg_dispatch_note_stats(int rows) { g_call.stats_rows = rows; }
 extern "C" void mseg_note_launch(const char* kernel, unsigned grid, unsigned block, int aux) {
   g_call.launches += 1;
   if (aux || g_call.name[0]) return;                  // the first non-helper kernel names the call

@@ -25,6 +25,7 @@ extern "C" void mseg_note_launch(const char* kernel, unsigned grid, unsigned blo
 extern "C" void mseg_dispatch_begin(int dry);
 extern "C" void mseg_dispatch_end(MsegKernelInfo* info);
 extern "C" void mseg_dispatch_note(int precision, size_t workspace);
+extern "C" void mseg_dispatch_note_stats(int rows);
 #define MSEG_KL(K, grid_, block_, shmem_, st_, ...)                                              \
   do {                                                                                           \
     mseg_note_launch(#K, (unsigned)(grid_).x, (unsigned)(block_).x, 0);                          \

@@ -52,7 +52,8 @@ struct P8Cfg {
   // room for four.
   static constexpr int RING = BN == 128 ? 6 : 4;
   static constexpr int P = RING - 2;
-  static constexpr int LDS_BYTES = 2 * HALO_BYTES + RING * SLOT_BYTES + 2 * TAB_BYTES;
+  static constexpr int BIAS_BYTES = 8 * 256;             // per wave: the bias of its 64 output channels (epilogue)
+  static constexpr int LDS_BYTES = 2 * HALO_BYTES + RING * SLOT_BYTES + 2 * TAB_BYTES + BIAS_BYTES;
 };
 
 // one 1 KB piece (16 weight rows of 64 bytes) of a weight slab by LDS-DMA
@@ -72,9 +73,21 @@ __device__ __forceinline__ void p8_issue_w(const void* w, unsigned wbytes, char*
 // 160 x 160: 120 of 346 us were the stores).
 // Same semantics as igemm_epilogue for what this kernel is launched on: plain epilogue, linear pixel order, bias, two
 // destinations split at a multiple of 64 channels, optional accumulation into the destination, bf16 or fp32 tensors.
-template <typename Cfg>
+// ST: the launch also takes the statistics of the normalisation that follows (MsegIgemm.stats): per wave and tile the sums
+// of act(z) and act(z)^2 over the wave's live pixels, z as stored, for its 64 channels -> stats[srow][0 / 1][channel].  A
+// lane holds 16 channels of ONE pixel per MFMA block, so the sum over pixels is a sum over lanes: the 32 per-lane values
+// (16 channels x 2 statistics, accumulated over the wave's MB blocks first) go through a five-step halving butterfly
+// (ds_swizzle, xor 16 .. 1: each step a lane keeps the half of its list its lane bit selects and adds the partner's copy of
+// that half) that leaves ONE total per lane — fixed summation tree, no atomics.
+template <int MASK>
+__device__ __forceinline__ float p8_swizzle_xor(float x) {      // x of lane (l ^ MASK), within groups of 32 lanes
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), (MASK << 10) | 0x1f));
+}
+
+template <typename Cfg, bool ST>
 __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int cw /* first channel of this wave */, int wm,
-                                            int lane, int TW, int TH, int img, int oy0, int ox0) {
+                                            int lane, int TW, int TH, int img, int oy0, int ox0, int srow,
+                                            char* bias_lds /* this wave's 256 bytes */, int& staged_cw) {
   const int li = lane & 31, lh = lane >> 5;
   const MsegIgemm* pe = (const MsegIgemm*)__builtin_amdgcn_kernarg_segment_ptr();  // kernel argument 0 (kept out of the
   asm volatile("" : "+s"(pe));                                                     // K-loop's SGPRs, like igemm_epilogue)
@@ -88,6 +101,74 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
   const int ld = second ? pe->ld1 : pe->ld0;
   const int accf = second ? pe->acc1 : pe->acc0;
   const int noff = cw - (second ? e_split : 0);
+  // The bias of this wave's 64 channels sits in LDS (one memory round trip per channel-tile change of the persistent walk —
+  // usually one per kernel — instead of two per tile); written and read by this wave only: no barrier.
+  if (e_bias && staged_cw != cw) {
+    *reinterpret_cast<float*>(bias_lds + lane * 4) = *(const __attribute__((address_space(1))) float*)(e_bias + cw + lane);
+    staged_cw = cw;
+  }
+  if (ST) {
+    // Statistics FIRST, as a pass of its own over the accumulators (nothing of this tile is in the vector-memory queue
+    // yet), one channel quad at a time: 8 running sums per lane.  The bias is added to the accumulators IN PLACE (the store
+    // pass below then adds none).  ReLU and the masking of dead rows are ONE v_med3 with per-row bounds.
+    float* const e_stats = pe->stats;
+    const float lo_live = pe->stats_act == MSEG_ACT_RELU ? 0.f : -__builtin_inff();
+    float lo_a[Cfg::MB], hi_a[Cfg::MB];
+#pragma unroll
+    for (int a = 0; a < Cfg::MB; ++a) {
+      const int i = wm * Cfg::TM + a * 32 + li;
+      const int iy = i / TW;
+      const bool ok = (iy < TH) & (oy0 + iy < e_H);
+      lo_a[a] = ok ? lo_live : 0.f;
+      hi_a[a] = ok ? __builtin_inff() : 0.f;
+    }
+    const bool u16 = (li & 16) != 0, u8 = (li & 8) != 0, u4 = (li & 4) != 0;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int b = 0; b < Cfg::NB; ++b) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                    // channel quad g: accumulator registers 4 g .. 4 g + 3
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (e_bias) bias4 = *reinterpret_cast<const f32x4*>(bias_lds + (b * 32 + 8 * g + 4 * lh) * 4);
+        f32x4 S = {0.f, 0.f, 0.f, 0.f}, Q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < Cfg::MB; ++a) {
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            float x0 = acc[a][b][4 * g + k] + bias4[k], x1 = acc[a][b][4 * g + k + 1] + bias4[k + 1];
+            acc[a][b][4 * g + k] = x0; acc[a][b][4 * g + k + 1] = x1;
+            if (e_d16) {                               // the values as the store below rounds them
+              const unsigned d = pack_bf16x2(x0, x1);
+              x0 = bf16_lo(d); x1 = bf16_hi(d);
+            }
+            x0 = __builtin_amdgcn_fmed3f(x0, lo_a[a], hi_a[a]);
+            x1 = __builtin_amdgcn_fmed3f(x1, lo_a[a], hi_a[a]);
+            S[k] += x0; S[k + 1] += x1;
+            Q[k] = fmaf(x0, x0, Q[k]); Q[k + 1] = fmaf(x1, x1, Q[k + 1]);
+          }
+        }
+        // Sum over the 32 lanes that hold the same channels (a lane = one pixel): halving butterfly — in each step a lane
+        // keeps the half of its list its lane bit selects and adds the partner's copy of that half — down to one value,
+        // then two plain exchange-and-add steps.  Fixed summation tree.
+        const f32x4 s4 = u16 ? S : Q, k4 = u16 ? Q : S;
+        f32x4 g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g4[j] = p8_swizzle_xor<16>(s4[j]);
+        const f32x4 w4 = k4 + g4;
+        const f32x2 lo2 = w4.lo, hi2 = w4.hi;
+        const f32x2 s2 = u8 ? lo2 : hi2, k2 = u8 ? hi2 : lo2;
+        f32x2 g2;
+        g2[0] = p8_swizzle_xor<8>(s2[0]); g2[1] = p8_swizzle_xor<8>(s2[1]);
+        const f32x2 w2 = k2 + g2;
+        float t = (u4 ? w2[1] : w2[0]) + p8_swizzle_xor<4>(u4 ? w2[0] : w2[1]);
+        t += p8_swizzle_xor<2>(t);
+        t += p8_swizzle_xor<1>(t);
+        // lanes with equal bits 4, 3, 2 now hold statistic (li >> 4) of channel 2 bit3 + bit2 of the quad
+        if ((li & 3) == 0)
+          e_stats[((size_t)srow * 2 + (li >> 4)) * e_Ngemm + cw + b * 32 + 8 * g + 4 * lh + ((li >> 2) & 3)] = t;
+      }
+    }
+  }
 #pragma unroll
   for (int b = 0; b < Cfg::NB; ++b) {
     float4 bq[4];
@@ -95,8 +176,8 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
     for (int g = 0; g < 4; ++g)
     {
       bq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e_bias) {
-        const f32x4 t = *(const __attribute__((address_space(1))) f32x4*)(e_bias + cw + b * 32 + 8 * g + 4 * lh);
+      if (e_bias && !ST) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + (b * 32 + 8 * g + 4 * lh) * 4);
         bq[g] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
@@ -148,7 +229,7 @@ __device__ __forceinline__ void p8_epilogue(f32x16 (&acc)[Cfg::MB][Cfg::NB], int
   }
 }
 
-template <int BM, int BN, int TR>
+template <int BM, int BN, int TR, bool ST>
 __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, const P8Tile tg, int m_fastest, int ntiles, int dbg) {
   using Cfg = P8Cfg<BM, BN>;
   constexpr int HL = Cfg::HL, NP = Cfg::NP, RING = Cfg::RING, P = Cfg::P;
@@ -158,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, con
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   char* const ring = lds + 2 * Cfg::HALO_BYTES;
   char* const tabs = ring + Cfg::RING * Cfg::SLOT_BYTES;
+  char* const bias_lds = tabs + 2 * Cfg::TAB_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,7 +311,9 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, con
   unsigned w_n0off = 0u;
   unsigned hvalid = 0u;
   int c_img = 0, c_oy0 = 0, c_ox0 = 0, c_n0 = 0;
+  int staged_cw = -1;                                  // first channel of the bias this wave holds in LDS
 
+  auto tile_m_of = [&](int t) { return m_fastest ? t % ntiles_m : t / ntiles_n; };
   auto tile_coords = [&](int t, int& img, int& oy0, int& ox0, int& n0) {
     const int tile_m = m_fastest ? t % ntiles_m : t / ntiles_n;
     const int tile_n = m_fastest ? t / ntiles_m : t - tile_m * ntiles_n;
@@ -465,7 +549,8 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, con
     if (dbg & 1) {                                       // timing ablation: no stores (one element keeps the MFMAs alive)
       if (acc[0][0][0] == 12345.678f) p.dst0[0] = acc[1][1][3];
     } else {
-      p8_epilogue<Cfg>(acc, c_n0 + wn * 64, wm, lane, TW, TH, c_img, c_oy0, c_ox0);
+      p8_epilogue<Cfg, ST>(acc, c_n0 + wn * 64, wm, lane, TW, TH, c_img, c_oy0, c_ox0, ST ? tile_m_of(t) * Cfg::WM + wm : 0,
+                           bias_lds + wave * 256, staged_cw);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -517,13 +602,20 @@ int igemm_p8_try(const MsegIgemm& p, int tr, int m_fastest, int cus, hipStream_t
   if (p.bias && ((uintptr_t)p.bias & 15)) return 0;
   if (p.nsrc > 1 && (p.src[0].C % KC) != 0) return 0;
   if ((long long)p.Hi * p.Wi < 256) return 0;
+  // statistics for the following normalisation (MsegIgemm.stats): plain / ReLU operand forms, one destination written once
+  const bool stats = p.stats && tr != 2 && p.split >= p.Ngemm && !p.acc0 &&
+                     (p.stats_act == MSEG_ACT_NONE || p.stats_act == MSEG_ACT_RELU);
 #define P8_LAUNCH(BM_, BN_, tiles_)                                                                                    \
   do {                                                                                                                 \
     const long long nt_ = (tiles_) * ((p.Ngemm + BN_ - 1) / BN_);                                                      \
     const dim3 grid((unsigned)(nt_ < cus ? nt_ : cus));                                                                \
-    if (tr == 0) MSEG_KL((igemm_p8_kernel<BM_, BN_, 0>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);    \
-    else if (tr == 1) MSEG_KL((igemm_p8_kernel<BM_, BN_, 1>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8); \
-    else MSEG_KL((igemm_p8_kernel<BM_, BN_, 2>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);            \
+    if (stats && (tiles_) * P8Cfg<BM_, BN_>::WM > 0x7fffffffLL) return 0;                                               \
+    if (stats) mseg_dispatch_note_stats((int)((tiles_) * P8Cfg<BM_, BN_>::WM));                                         \
+    if (stats && tr == 0) MSEG_KL((igemm_p8_kernel<BM_, BN_, 0, true>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8); \
+    else if (stats) MSEG_KL((igemm_p8_kernel<BM_, BN_, 1, true>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8); \
+    else if (tr == 0) MSEG_KL((igemm_p8_kernel<BM_, BN_, 0, false>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);    \
+    else if (tr == 1) MSEG_KL((igemm_p8_kernel<BM_, BN_, 1, false>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8); \
+    else MSEG_KL((igemm_p8_kernel<BM_, BN_, 2, false>), grid, dim3(512), 0, st, p, tg, m_fastest, (int)nt_, g_p8_on >> 8);            \
     MSEG_LAUNCH_CHECK();                                                                                               \
   } while (0)
   P8Tile tg;

@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
                                                            float* __restrict__ m, float* __restrict__ v,
                                                            float* __restrict__ vmax, size_t n, float step_size,
                                                            float w1, float beta2, float w2, float eps,
-                                                           float bc2_sqrt) {
+                                                           float bc2_sqrt, const float* __restrict__ derived) {
+  if (derived) {                                  // device-side step counter (capturable form): see adam_advance_kernel
+    step_size = derived[0];
+    bc2_sqrt = derived[1];
+  }
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)vmax)) & 15) == 0;
@@ -252,7 +256,39 @@ extern "C" int mseg_adam_amsgrad_step(float* p, const float* g, float* m, float*
   if (blocks > 256u * 16u) blocks = 256u * 16u;      // 16 workgroups of 4 waves per CU, grid-stride
   hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
                      n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)sqrt(bc2));
+                     (float)sqrt(bc2), (const float*)nullptr);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// The same update with the step counter and the learning rate ON THE DEVICE, so that the launch carries no per-step host
+// scalar and a hipGraph of the training step can be replayed (torch's `capturable=True` idea, without its per-tensor
+// launches).  state = 4 doubles: [0] lr (written by the host when a scheduler changes it), [1] step count (advanced here),
+// [2..3] two floats each widened to a double slot: lr / (1 - beta1^step) and sqrt(1 - beta2^step), rounded to fp32 once
+// like the host form above.
+__global__ void adam_advance_kernel(double* __restrict__ state, double beta1, double beta2) {
+  if (threadIdx.x || blockIdx.x) return;
+  const double step = state[1] + 1.0;
+  state[1] = step;
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  float* d = reinterpret_cast<float*>(state + 2);
+  d[0] = (float)(state[0] / bc1);
+  d[1] = (float)sqrt(bc2);
+}
+
+extern "C" int mseg_adam_amsgrad_step_dev(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
+                                          double* state, double beta1, double beta2, double eps, void* stream) {
+  if (!p || !g || !m || !v || !vmax || !state || n == 0) return MSEG_EINVAL;
+  if ((uintptr_t)state & 7) return MSEG_EINVAL;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256u * 16u) blocks = 256u * 16u;
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+  MSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax,
+                     n, 0.f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 1.f,
+                     (const float*)(state + 2));
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

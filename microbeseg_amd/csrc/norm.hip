@@ -48,7 +48,8 @@ extern "C" size_t mseg_norm_workspace_bytes(int N, int HW, int C) {
   NormGeom g4 = norm_geom(N, HW, C, 4), g8 = norm_geom(N, HW, C, 8);
   const int chunks = g4.chunks > g8.chunks ? g4.chunks : g8.chunks;
   // arrival counters + fp64 partials [N][chunks][3][C] + per-(n,c) sums [3][N][C] + fp32 k-tables [3][N][C] (2*N*C doubles)
-  return NORM_CTR_BYTES + ((size_t)N * chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C) * sizeof(double);
+  // (+ [2][16][C] slice sums of mseg_norm_stats_from_conv)
+  return NORM_CTR_BYTES + ((size_t)N * chunks * 3 * C + (size_t)3 * N * C + (size_t)2 * N * C + (size_t)32 * C) * sizeof(double);
 }
 
 // V consecutive channels (V = 4: fp32 storage, V = 8: bf16 storage) at element offset e.  Loaded values stay in their 16 raw
@@ -448,7 +449,7 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom
                                          float* __restrict__ scale, float* __restrict__ shift,
                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         float momentum) {
+                                         float momentum, double count) {
   const double* S = nc;
   const double* Q = nc + (size_t)g.N * g.C;
   if (norm == MSEG_NORM_BN) {
@@ -458,7 +459,8 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom
       // trips = 11 us, 114 such launches per step; the order of the additions is unchanged)
 #pragma unroll 8
       for (int n = 0; n < g.N; ++n) { s += S[(size_t)n * g.C + c]; q += Q[(size_t)n * g.C + c]; }
-      const double cnt = (double)g.N * g.HW;
+      // (count > 0: the g.N "samples" are row slices of a convolution's partial sums, mseg_norm_stats_from_conv)
+      const double cnt = count > 0.0 ? count : (double)g.N * g.HW;
       const double mean = s / cnt;
       double var = q / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -651,7 +653,55 @@ extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int
   MSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(nblocks(norm == MSEG_NORM_BN ? C : (size_t)N * C)), dim3(256), 0,
                      st, (const double*)nc, g, norm, gamma, beta, eps, scale, shift, mean, rstd, running_mean,
-                     running_var, momentum);
+                     running_var, momentum, 0.0);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+// ---- statistics from a convolution's epilogue (MsegIgemm.stats) ------------------------------------------------------------
+// part[rows][2][C] fp32 (one row per pixel tile and wave row of the producing kernel) -> nc[s][slice][c] fp64: the rows are
+// cut into CONV_STAT_SLICES contiguous slices, a workgroup sums 32 channels of one slice and one statistic (8 thread groups
+// stride the slice, combined through LDS in fixed order); norm_fwd_finalize_kernel then adds the slices like samples.
+#define CONV_STAT_SLICES 16
+__global__ __launch_bounds__(256) void conv_stats_reduce_kernel(const float* __restrict__ part, double* __restrict__ nc,
+                                                                int rows, int C, int rows_per_slice) {
+  __shared__ double red[8][32];
+  const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + o, slice = blockIdx.y, s = blockIdx.z;
+  const int r0 = slice * rows_per_slice;
+  const int r1 = r0 + rows_per_slice < rows ? r0 + rows_per_slice : rows;
+  double acc = 0.0;
+  if (c < C) {
+    const float* base = part + (size_t)s * C + c;
+#pragma unroll 4
+    for (int r = r0 + kg; r < r1; r += 8) acc += (double)base[(size_t)r * 2 * C];
+  }
+  red[kg][o] = acc;
+  __syncthreads();
+  if (kg == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][o];
+    nc[((size_t)s * CONV_STAT_SLICES + slice) * C + c] = t;
+  }
+}
+
+extern "C" int mseg_norm_stats_from_conv(const float* part, int rows, int C, long long count, const float* gamma,
+                                         const float* beta, float eps, float* scale, float* shift, float* mean,
+                                         float* rstd, float* running_mean, float* running_var, float momentum, void* ws,
+                                         void* stream) {
+  if (!part || !scale || !shift || !mean || !rstd || !ws || rows <= 0 || C <= 0 || count <= 0) return MSEG_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* nc = (double*)((char*)ws + NORM_CTR_BYTES);
+  const int rps = (rows + CONV_STAT_SLICES - 1) / CONV_STAT_SLICES;
+  hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((C + 31) / 32, CONV_STAT_SLICES, 2), dim3(256), 0, st, part, nc, rows,
+                     C, rps);
+  MSEG_LAUNCH_CHECK();
+  NormGeom g = {};
+  g.N = CONV_STAT_SLICES; g.HW = 1; g.C = C;         // (slices past the last row hold zeros: their loops are empty)
+  hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3(nblocks(C)), dim3(256), 0, st, (const double*)nc, g, MSEG_NORM_BN,
+                     gamma, beta, eps, scale, shift, mean, rstd, running_mean, running_var, momentum, (double)count);
   MSEG_LAUNCH_CHECK();
   return MSEG_OK;
 }

@@ -366,7 +366,8 @@ def repack_all(params):
             entries += [e for _, e in sorted(packs.items())]
     if not entries:
         return 0
-    key = tuple((id(e), e.param.data_ptr(), e.t.data_ptr(), 0 if e._t16 is None else e._t16.data_ptr()) for e in entries)
+    key = tuple((id(e), e.param.data_ptr(), e.t.data_ptr(), 0 if e._t16 is None else e._t16.data_ptr(), e.job)
+                for e in entries)         # (the geometry too: ids and allocator addresses are reused across networks)
     tab = _pack_tables.get(key)
     if tab is None:
         _pack_tables.clear()                        # one live network per process is the common case
@@ -388,14 +389,24 @@ def repack_all(params):
     return len(entries)
 
 
+def mark_packs_fresh(params):
+    """the packed operands of `params` were refreshed on the device by a replayed hipGraph (its recorded repack_all)"""
+    for p in params:
+        packs = p.__dict__.get("_mseg_packs")
+        if packs:
+            for e in packs.values():
+                e.mark_fresh()
+
+
 class KernelChoice:
     """the library's answer to "which kernel does this launch take" (MsegKernelInfo)"""
-    __slots__ = ("name", "bf16", "launches", "grid", "block", "workspace")
+    __slots__ = ("name", "bf16", "launches", "grid", "block", "workspace", "stats_rows")
 
     def __init__(self, info):
         self.name = info.name.decode()
         self.bf16 = info.precision == 1
         self.launches, self.grid, self.block, self.workspace = info.launches, info.grid, info.block, info.workspace
+        self.stats_rows = info.stats_rows
 
     def __repr__(self):
         return f"KernelChoice({self.name!r}, bf16={self.bf16}, grid={self.grid})"
@@ -451,9 +462,25 @@ def _igemm_bf16_ok(p):
     return ok
 
 
+# BatchNorm statistics taken in the producing convolution's epilogue where its kernel can (MsegIgemm.stats, igemm_p8.hip)
+# instead of by a pass over the stored tensor.  Measured round 3 (bf16, 320x320, batch 32, one box, rocprofv3): the 20 layers
+# concerned lose 3.85 ms of statistics passes per 7 steps and their convolutions gain 4.6 ms (the epilogue of the
+# one-workgroup-per-CU kernel is on its critical path: + 6 % on 256 x 256 tiles, + 21 % on 512 x 128) — a wash, so it is
+# off by default; MSEG_CONV_STATS=1 / set_conv_stats(True) turn it on.
+_conv_stats = os.environ.get("MSEG_CONV_STATS", "0") == "1"
+
+
+def set_conv_stats(flag):
+    global _conv_stats
+    old, _conv_stats = _conv_stats, bool(flag)
+    return old
+
+
 def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, dst0, ld0, acc0=0,
           dst1=None, ld1=0, acc1=0, split=None, epi=EPI_PLAIN, Cq=0, morder=MORDER_LINEAR, real_cin=None,
-          precision=None):
+          precision=None, stats=None):
+    """`stats`: None, or (activation of the output, Workspace) — the caller would like the statistics of act(output) from
+    this launch.  Returns None, or (partial-sum tensor, rows) when the kernel the library chose has taken them."""
     lib = _lib.load()
     p = MsegIgemm()
     _fill_igemm(p, srcs, w.Kpad, w.Npad, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, ld0, acc0, ld1, acc1, split, epi,
@@ -476,9 +503,21 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
             buf = torch.empty(need, dtype=torch.uint8, device=dst0.device)
             _splitk_ws[key] = buf
         p.ws, p.ws_bytes = buf.data_ptr(), buf.numel()
+    taken = None
+    if stats is not None and bf16 and _conv_stats:
+        # ask the dispatch (the same code the launch runs) whether its kernel for this descriptor takes statistics
+        p.stats, p.stats_act = _DUMMY, stats[0]
+        choice = _query(lib.mseg_igemm_query, p)
+        rows = choice.stats_rows if choice else 0
+        if rows > 0:
+            part = stats[1].get("convstats", rows * 2 * Ngemm * 4)
+            p.stats = part.data_ptr()
+            taken = (part, rows)
+        else:
+            p.stats = None
     if _timer is None:
         check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
-        return
+        return taken
     flops = 2.0 * NB * Ho * Wo * Ngemm * (p.Cin if real_cin is None else real_cin) * KH * KW
     if mode == MODE_TCONV:
         flops /= stride * stride
@@ -487,6 +526,7 @@ def igemm(srcs, w, bias, NB, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode, Ngemm, d
     e0.record()
     check(lib.mseg_igemm(C.byref(p), _stream()), "igemm")
     e1.record()
+    return taken
 
 
 def _fill_wgrad(p, P, Qs, NB, Hp, Wp, Hq, Wq, KH, KW, stride, pad, nch_store):
@@ -559,8 +599,10 @@ def note_training_step():
     _stats_epoch += 1
 
 
-def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws):
-    """Fill node.scale/shift (+mean/rstd) from a = act(z); BatchNorm eval mode uses the running statistics."""
+def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws, conv_part=None):
+    """Fill node.scale/shift (+mean/rstd) from a = act(z); BatchNorm eval mode uses the running statistics.
+    `conv_part`: (partial sums, rows) left by the producing convolution's epilogue (training BatchNorm): the tensor is not
+    read again."""
     lib = _lib.load()
     dev = node.z.device
     node.norm = norm
@@ -601,10 +643,16 @@ def norm_stats(node, norm, gamma, beta, running_mean, running_var, training, ws)
         node.rstd = torch.empty(N * ng, dtype=torch.float32, device=dev)
         running_mean = running_var = None
     w = ws.get("norm", lib.mseg_norm_workspace_bytes(N, HW, Cc), zero=True)
-    check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, norm, _ptr(gamma), _ptr(beta), BN_EPS,
-                              node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
-                              node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
-                              _ptr(node.a), w.data_ptr(), _stream()), "norm_stats")
+    if conv_part is not None and norm == NORM["bn"] and not expensive:
+        check(lib.mseg_norm_stats_from_conv(conv_part[0].data_ptr(), conv_part[1], Cc, N * HW, _ptr(gamma), _ptr(beta),
+                                            BN_EPS, node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
+                                            node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
+                                            w.data_ptr(), _stream()), "norm_stats_from_conv")
+    else:
+        check(lib.mseg_norm_stats(node.z.data_ptr(), N, HW, Cc, _st(node.z), node.act, norm, _ptr(gamma), _ptr(beta),
+                                  BN_EPS, node.scale.data_ptr(), node.shift.data_ptr(), node.mean.data_ptr(),
+                                  node.rstd.data_ptr(), _ptr(running_mean), _ptr(running_var), BN_MOMENTUM,
+                                  _ptr(node.a), w.data_ptr(), _stream()), "norm_stats")
     if running_mean is not None:
         # the kernel updated the running statistics through raw pointers: tell torch, and start a new epoch of the eval-mode
         # table cache above (a recorded step replayed by a hipGraph runs no Python: graph_step.py calls note_training_step)
@@ -724,6 +772,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
     n0 = in_nodes[0]
     N, Hi, Wi = n0.N, n0.H, n0.W
     dev = n0.z.device
+    conv_part = None          # (partial sums, rows) when the convolution's epilogue has taken the BatchNorm statistics
     if isinstance(n0.z, RawFrame):
         srcs = []
     cin_total = sum(n.C for n in in_nodes)
@@ -759,7 +808,10 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
                                                   Wi, cin, cout, z.data_ptr(), _st(z), _stream()), "first_conv_fwd")
         else:
             wp = pack_weight(conv.weight, 9, cout, cin, 1, cin * 9, 9, kind="fwd")
-            igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin)
+            want = (spec.act, ws) if (training and spec.norm == NORM["bn"] and
+                                      spec.act in (ACT["none"], ACT["relu"])) else None
+            conv_part = igemm(srcs, wp, bias, N, Hi, Wi, Ho, Wo, 3, 3, stride, 1, MODE_CONV, cout, z, cout, real_cin=cin,
+                              stats=want)
         act = spec.act
     node = Node(z, N, Ho, Wo, cout)
     node.act = act
@@ -768,7 +820,7 @@ def _run_conv(spec, in_nodes, training, ws, tape, first_layer_cin=None, st=torch
     nm = spec.norm_mod
     if spec.norm == NORM["bn"]:
         norm_stats(node, spec.norm, nm.weight.detach(), nm.bias.detach(), nm.running_mean, nm.running_var,
-                   training, ws)
+                   training, ws, conv_part=conv_part)
         if training:
             _nbt_pending.append(nm.num_batches_tracked)    # all layers' counters advance in ONE launch (end of forward)
     elif spec.norm == NORM["gn"]:
@@ -929,6 +981,11 @@ def get_wgrad_overlap():
     return _wgrad_overlap
 
 
+# inside a hipGraph capture the side stream joins the capture at its first wait and leaves it at the join of backward():
+# the recorded step keeps the two branches
+_overlap_in_capture = os.environ.get("MSEG_OVERLAP_IN_CAPTURE", "0") == "1"
+
+
 # measured round 3 (bf16 320x320 batch 32): 39.5-39.7 ms/step with it, 39.3-39.4 without — every launch of this path already
 # fills the chip, two streams only interleave them.  Off by default; kept as a switch for smaller crops.
 _decoder_overlap = os.environ.get("MSEG_DECODER_OVERLAP", "0") == "1"
@@ -977,7 +1034,7 @@ def backward(spec, tape, grad_outs, ws, on_grads=None, direct=None):
     # (bf16 mode only: there the step has long HBM-bound stretches next to short matrix kernels; the fp32 step is matrix-core
     # bound almost everywhere and measured 0.8 % slower with the second stream)
     if _wgrad_overlap and _precision == "bf16" and on_grads is None and dev.type == "cuda" and \
-            not torch.cuda.is_current_stream_capturing():
+            (_overlap_in_capture or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_side_stream(dev)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)                           # nothing of this pass runs ahead of what is already queued

@@ -6,10 +6,11 @@ hipGraph on ROCm) and replays it: the batch is copied into static input tensors,
 optimizer state — lives in the graph's private memory pool at fixed addresses.
 
 Rules of the capture (all met by this build's step): no host synchronisation inside the step (losses stay device
-scalars), every kernel on the capturing stream (the C ABI takes the stream from torch), a capturable optimizer
-(``torch.optim.Adam(..., capturable=True)``: step counters on the device).  The learning rate is baked into the graph, so
-``set_lr`` re-records it (ReduceLROnPlateau fires a few times per training).  Single-GPU only: the data-parallel wrapper
-overlaps RCCL all-reduces with the backward pass, which is left to the eager path.
+scalars), every kernel on the capturing stream (the C ABI takes the stream from torch), a capturable optimizer:
+``training/optim.FusedAdam`` (step counter AND learning rate on the device: a scheduler's change reaches the recorded step
+through ``sync_device_scalars``, nothing is re-recorded) or ``torch.optim.Adam(..., capturable=True)`` (the rate is baked
+into the graph, ``set_lr`` re-records it).  Single-GPU only: the data-parallel wrapper overlaps RCCL all-reduces with the
+backward pass, which is left to the eager path.
 The first ``warmup`` calls run eagerly (workspaces, lazily built tables and the optimizer state must exist before the
 capture) — with real batches, so the trajectory is the eager one.
 """
@@ -52,7 +53,8 @@ class GraphedTrainStep:
     def set_lr(self, lr):
         for group in self.optimizer.param_groups:
             group["lr"] = lr
-        self.invalidate()
+        if not hasattr(self.optimizer, "sync_device_scalars"):
+            self.invalidate()
 
     def __call__(self, *batch):
         self.calls += 1
@@ -66,12 +68,33 @@ class GraphedTrainStep:
         # call may well be the short last batch of an epoch, and recording that shape would leave every full batch eager
         if self.shapes is not None and self._signature(batch) != self.shapes:
             return self.step_fn(*batch)              # e.g. the last, smaller batch of an epoch: eager
+        fused = hasattr(self.optimizer, "sync_device_scalars")
+        if fused:
+            self.optimizer.sync_device_scalars()     # learning rate / step count as the host sees them now
         if self.graph is None:
-            self._capture(batch)
+            self._capture(batch)                     # (records only; the replay below is the step)
+            if fused:
+                self._rewind_capture_bookkeeping()
         else:
             for s, b in zip(self.static_in, batch):
                 if s is not None:
                     s.copy_(b, non_blocking=True)
         self.graph.replay()
         engine.note_training_step()                  # the replay updated running statistics without running any Python
+        if fused:
+            self.optimizer.note_replayed_step()
+        else:
+            # the parameters changed without their version counters moving: anything cached against them (the packed GEMM
+            # operands of engine.py) must look stale to the next eager forward
+            torch.autograd.graph.increment_version([p for g in self.optimizer.param_groups for p in g["params"]])
         return self.static_loss
+
+    def _rewind_capture_bookkeeping(self):
+        """FusedAdam.step() ran (in Python) while the step was being recorded and counted a step that no kernel has
+        executed yet"""
+        opt = self.optimizer
+        for (_, ps, _, _), ds in zip(opt._groups, opt._dev_state):
+            step = opt.state[ps[0]]["step"] - 1
+            for p in ps:
+                opt.state[p]["step"] = step
+            ds[2] = step

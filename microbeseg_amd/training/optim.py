@@ -13,7 +13,10 @@ the network out for the update:
 * the explicit backward of ``engine.py`` writes each gradient straight into its arena view (``p.grad`` is allocated
   once and never freed: ``zero_grad`` only marks it as consumed), so no gradient is copied or accumulated by autograd;
 * right after the update all packed GEMM operands of the convolutions are refreshed in one launch
-  (``engine.repack_all``), the next forward / backward finds them current.
+  (``engine.repack_all``), the next forward / backward finds them current;
+* the step counter and the learning rate the kernel uses live on the device (``mseg_adam_amsgrad_step_dev``): a step has
+  no per-step host scalar, so ``training/graph_step.py`` can record it in a hipGraph and replay it.  ``state[p]['step']``
+  stays a host integer (the stock optimizer's state layout); a replayed step is counted through ``note_replayed_step``.
 """
 import torch
 from torch.optim.optimizer import Optimizer
@@ -37,6 +40,7 @@ class FusedAdam(Optimizer):
         # per param group: (index into self.param_groups, params, arenas, length).  The INDEX, not the dict:
         # load_state_dict replaces the group dicts, and schedulers edit the ones in self.param_groups
         self._groups = []
+        self._dev_state = []
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
             if not ps:
@@ -66,7 +70,34 @@ class FusedAdam(Optimizer):
                     st["exp_avg"] = fm[o:o + k].view_as(p)
                     st["exp_avg_sq"] = fv[o:o + k].view_as(p)
                     st["max_exp_avg_sq"] = fx[o:o + k].view_as(p)
+            # [lr, steps done, scratch, scratch] for mseg_adam_amsgrad_step_dev
+            dev_state = torch.tensor([float(group["lr"]), 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
             self._groups.append((gi, ps, flat, n))
+            self._dev_state.append([dev_state, float(group["lr"]), 0])     # tensor, lr and step count it holds
+
+    def sync_device_scalars(self):
+        """Bring the device copies of (learning rate, step count) in line with ``param_groups`` / ``state``.  step() does it
+        itself; a replayed hipGraph does not run step(), so GraphedTrainStep calls this before each replay (a scheduler may
+        have changed the rate, load_state_dict the count).  Must not be called while a stream is being captured with
+        changed values — the fill would be recorded — hence the assertion."""
+        for (gi, ps, _, _), ds in zip(self._groups, self._dev_state):
+            lr, step = float(self.param_groups[gi]["lr"]), int(self.state[ps[0]]["step"])
+            if lr != ds[1] or step != ds[2]:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedAdam: learning rate / step count changed inside a hipGraph capture")
+                ds[0][:2] = torch.tensor([lr, float(step)], dtype=torch.float64)      # one small H2D copy
+                ds[1], ds[2] = lr, step
+
+    def note_replayed_step(self):
+        """a recorded step() ran on the device without this object's step() being called"""
+        from .. import engine
+        for (_, ps, _, _), ds in zip(self._groups, self._dev_state):
+            step = self.state[ps[0]]["step"] + 1
+            for p in ps:
+                self.state[p]["step"] = step
+            ds[2] = step
+            torch.autograd.graph.increment_version(ps)
+            engine.mark_packs_fresh(ps)              # the recorded repack_all ran after the recorded update
 
     def zero_grad(self, set_to_none=True):
         """The gradient arena is persistent: the next backward overwrites it (set_to_none semantics without the frees)."""
@@ -101,7 +132,8 @@ class FusedAdam(Optimizer):
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
         from .. import engine
-        for gi, ps, (fp, fg, fm, fv, fx), n in self._groups:
+        self.sync_device_scalars()
+        for (gi, ps, (fp, fg, fm, fv, fx), n), ds in zip(self._groups, self._dev_state):
             group = self.param_groups[gi]                # looked up per step: lr schedulers / load_state_dict edit THESE
             # written since zero_grad(): by the engine's backward (raw pointers: it clears the flag) or in place by the caller
             # (p.grad.copy_(...): the tensor's version counter moves)
@@ -115,20 +147,18 @@ class FusedAdam(Optimizer):
                                    "zero_grad() (step() without backward, or an unused parameter)")
             step = self.state[ps[0]]["step"] + 1
             b1, b2 = group["betas"]
-            _lib.check(lib.mseg_adam_amsgrad_step(fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr(),
-                                                  fx.data_ptr(), n, float(group["lr"]), b1, b2, group["eps"], step,
-                                                  stream), "adam_amsgrad_step")
+            _lib.check(lib.mseg_adam_amsgrad_step_dev(fp.data_ptr(), fg.data_ptr(), fm.data_ptr(), fv.data_ptr(),
+                                                      fx.data_ptr(), n, ds[0].data_ptr(), b1, b2, group["eps"], stream),
+                       "adam_amsgrad_step_dev")
             for p in ps:
                 self.state[p]["step"] = step
+            ds[2] = step
             torch.autograd.graph.increment_version(ps)   # the kernel wrote through raw pointers
             engine.repack_all(ps)
         return loss
 
 
 def make_adam(params, lr=8e-4, capturable=False):
-    """The reference's Adam configuration (train.py:380-385).  FusedAdam, or — for hipGraph capture, which needs the
-    step counters on the device — torch's capturable implementation with the same hyper-parameters."""
-    if capturable:
-        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True,
-                                capturable=True)
+    """The reference's Adam configuration (train.py:380-385) as FusedAdam (eager or recorded in a hipGraph: its step
+    counter is on the device).  `capturable` is accepted for callers of earlier rounds and changes nothing."""
     return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)

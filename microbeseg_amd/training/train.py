@@ -135,9 +135,34 @@ class _Regime:
         else:
             self.scheduler = CosineAnnealingLR(self.optimizer, **r['cosine'](E))
         self._span = r['span'](self.epochs)
+        self._graphed = False                        # not decided yet (graphed_step)
 
     def after_validation(self, val_loss):
         self.scheduler.step(val_loss) if self.metric_driven else self.scheduler.step()
+
+    def graphed_step(self, net, criterion, distance, device, world):
+        """the training step of ``_run_phase`` as a replayed hipGraph, or None where that does not apply (several ranks: the
+        gradient all-reduce overlaps the backward pass eagerly; Ranger: host-side step logic; CPU).  Built once per run:
+        the recorded step stays valid across epochs — the learning rate is read from device memory."""
+        if self._graphed is False:
+            from .optim import FusedAdam
+            self._graphed = None
+            if world == 1 and torch.device(device).type == "cuda" and isinstance(self.optimizer, FusedAdam):
+                from .graph_step import GraphedTrainStep
+                opt = self.optimizer
+
+                def step(img, *labels):
+                    opt.zero_grad()
+                    if distance:
+                        border, cell = net(img)
+                        loss = criterion['border'](border, labels[0]) + criterion['cell'](cell, labels[1])
+                    else:
+                        loss = criterion(net(img), labels[0])
+                    loss.backward()
+                    opt.step()
+                    return loss
+                self._graphed = GraphedTrainStep(step, opt, warmup=2)
+        return self._graphed
 
     def percent(self, epochs_done, train_progress):
         return int(100 * epochs_done / self._span * train_progress[0] + 100 * train_progress[1])
@@ -320,6 +345,10 @@ class TrainWorker(QObject):
     is_training = False
     num_workers = None      # None: 0 on CPU, min(cpu_count // 2, 16) otherwise (the reference's rule)
     precision = "fp32"      # "bf16": bf16 matrix-core operands, fp32 accumulate / statistics (BASELINE configs[2])
+    graph_steps = False     # True: one GPU + Adam, the training step is recorded once and replayed (training/graph_step.py):
+                            # 0.1-0.2 ms of host time per step instead of 7-18 ms.  Off by default: measured round 3, a step is
+                            # GPU-bound even at batch 4 (bf16 8.0 ms eager with the weight gradients on a second stream,
+                            # 8.7-8.8 ms replayed) — the replay buys host time (GUI thread, data loader), not throughput
 
     @pyqtSlot()
     def stop_training_process(self):
@@ -458,12 +487,18 @@ class TrainWorker(QObject):
         loss_sum, seen = 0.0, 0
         loss = None
         batches = iter(loader)
+        graphed = regime.graphed_step(net, criterion, distance, device, world) if training and self.graph_steps else None
         for indices in plan.steps:
             if not indices:                          # validation step in which this rank's scatter chunk is empty
                 if not distance:
                     parallel.allreduce_dice_sums(torch.zeros(6, dtype=torch.float64, device=device), 0.0)
                 continue
             img, labels = feeder(next(batches), training)
+            if graphed is not None:
+                loss = graphed(img, *labels)
+                loss_sum += float(loss.item() * img.size(0))
+                seen += img.size(0)
+                continue
             regime.optimizer.zero_grad()
             with torch.set_grad_enabled(training):
                 if distance:

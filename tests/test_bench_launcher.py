@@ -34,17 +34,32 @@ def test_gpus_flag_must_match_the_launcher():
     assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
 
 
-def test_pmc_profile_is_selected_by_workload():
+def test_pmc_profile_is_selected_by_workload_and_kernel_sources(monkeypatch):
+    """roofline.traffic comes from a committed counter profile of the SAME workload taken on the SAME kernel sources
+    (tools/pmc_traffic.sh records bench.csrc_digest()); anything else is reported as stale / none, never as current."""
+    import glob
     sys.path.insert(0, str(ROOT))
     import bench
     import argparse
     a = argparse.Namespace(batch=32, size=256, arch="DU", act="relu", norm="bn", filters=[64, 1024], optimizer="adam",
                            precision="fp32")
+    monkeypatch.setattr(bench, "csrc_digest", lambda: "not-a-tree")
     got = bench.pmc_traffic("wgrad_halo9_kernel<3, 1>", a)
-    assert got["traffic"] and got["traffic"] > 1e8 and "bf16" not in got["traffic_source"]
-    assert got["traffic_source"] >= "profiles/r02b"      # the newest profile of the workload wins
-    a.precision, a.size = "bf16", 320
-    got = bench.pmc_traffic("igemm_halo_bf16w4_kernel<0, true>", a)      # bf16-stored operands (S16 form)
-    assert got["traffic"] and "bf16_320" in got["traffic_source"]
+    assert got["traffic"] is None and got["traffic_source"] == "stale" and got["traffic_stale_profile"].startswith("profiles/")
+    # a profile that records its source digest is used when (and only when) the digest matches
+    for f in sorted(glob.glob(str(ROOT / "profiles" / "*_hbm_traffic_pmc.json")), reverse=True):
+        tab = json.load(open(f))
+        cfg = dict(tab.get("__config__") or {})
+        sha = cfg.pop("csrc_sha", None)
+        if sha is None:
+            continue
+        a2 = argparse.Namespace(**{**vars(a), **{k: cfg[k] for k in ("batch", "size", "precision") if k in cfg}})
+        if bench.workload_key(a2) != cfg:
+            continue
+        kernel = next(k for k in tab if k != "__config__")
+        monkeypatch.setattr(bench, "csrc_digest", lambda sha=sha: sha)
+        got = bench.pmc_traffic(kernel, a2)
+        assert got["traffic"] == int(tab[kernel]["hbm_bytes_per_launch"]) and got["traffic_source"].startswith("profiles/")
+        break
     a.size = 512                               # no profile of that workload: say so instead of borrowing another one's
     assert bench.pmc_traffic("igemm_halo_bf16w4_kernel<0, true>", a) == {"traffic": None, "traffic_source": "none"}

@@ -1076,15 +1076,100 @@ def test_bf16_storage_256_pixel_tiles(eng, N, Cin, Cout, H, W, act, per_sample, 
     assert rel_err(got[0], got[1]) < 8e-3
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,in_act,out_act,dst16,want", [
+    (32, 128, 128, 96, 96, "relu", "relu", True, "igemm_p8_kernel<512, 128, 1, true>"),     # four wave rows per 512-pixel tile
+    (40, 64, 128, 48, 48, "none", "none", True, "igemm_p8_kernel<256, 128, 0, true>"),      # plain operand, no activation
+    (32, 128, 256, 72, 64, "relu", "relu", True, "igemm_p8_kernel<256, 256, 1, true>"),     # tile rows below the image
+    (40, 256, 512, 40, 40, "relu", "relu", True, "igemm_p8_kernel<256, 256, 1, true>"),     # image-wide tiles: 16 dead GEMM rows
+    (36, 512, 1024, 32, 32, "relu", "none", False, "igemm_p8_kernel<256, 256, 1, true>")])  # four channel tiles, fp32 output
+def test_conv_epilogue_statistics(eng, N, Cin, Cout, H, W, in_act, out_act, dst16, want):
+    """MsegIgemm.stats: the convolution's epilogue leaves per-tile sums of act(z) and act(z)^2 of the values AS STORED, and
+    mseg_norm_stats_from_conv turns them into the BatchNorm tables without reading z again.  Against mseg_norm_stats on the
+    stored tensor: the same sums in another order (fp32 over <= 128 pixels, then fp64), so tables, saved mean / rstd and
+    running statistics agree to fp32 rounding; z itself is bit-identical to a launch without statistics; the query
+    reports the partial rows, and a kernel without the feature reports none and leaves the buffer alone."""
+    import ctypes as C
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4100 + N + W)
+    z16 = _b16(rnd(g, N, Cin, H, W))
+    affine = in_act != "none"
+    scale = rnd(g, Cin) * 0.3 + 1.0 if affine else None
+    shift = rnd(g, Cin) * 0.1 if affine else None
+    w, b = rnd(g, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(g, Cout) * 0.5
+    wp = eng.pack_weight(w.cuda(), 9, Cout, Cin, 1, Cin * 9, 9)
+    node = _mk_node(eng, z16.float(), in_act, scale, shift, False)
+    node.z = node.z.to(torch.bfloat16)
+    srcs = [node.src()]
+    dt = torch.bfloat16 if dst16 else torch.float32
+    ws = eng.Workspace(torch.device("cuda"))
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=dt)
+    old = eng.set_conv_stats(True)
+    try:
+        taken = eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, out, Cout, precision="bf16",
+                          stats=(eng.ACT[out_act], ws))
+    finally:
+        eng.set_conv_stats(old)
+    torch.cuda.synchronize()
+    assert lib.mseg_last_kernel().decode() == want
+    assert taken is not None
+    part, rows = taken
+    tiles = {512: 4, 256: 2}[int(want.split("<")[1].split(",")[0])]          # wave rows per tile (P8Cfg::WM)
+    assert rows % tiles == 0 and rows * 2 * Cout * 4 <= part.numel() * part.element_size()
+    plain = torch.full_like(out, float("nan"))
+    assert eng.igemm(srcs, wp, b.cuda(), N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, plain, Cout,
+                     precision="bf16") is None
+    assert torch.equal(out, plain), "the statistics must not change what is stored"
+    gamma, beta = (rnd(g, Cout) * 0.2 + 1.0).cuda(), (rnd(g, Cout) * 0.1).cuda()
+    res = []
+    for fused in (True, False):
+        t = {k: torch.empty(Cout, device="cuda") for k in ("scale", "shift", "mean", "rstd")}
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        nws = ws.get("norm", lib.mseg_norm_workspace_bytes(N, H * W, Cout), zero=True)
+        if fused:
+            rc = lib.mseg_norm_stats_from_conv(part.data_ptr(), rows, Cout, N * H * W, gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                               t["scale"].data_ptr(), t["shift"].data_ptr(), t["mean"].data_ptr(),
+                                               t["rstd"].data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, nws.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = lib.mseg_norm_stats(out.data_ptr(), N, H * W, Cout, _lib.ST_BF16 if dst16 else _lib.ST_F32, eng.ACT[out_act],
+                                     eng.NORM["bn"], gamma.data_ptr(), beta.data_ptr(), 1e-5, t["scale"].data_ptr(),
+                                     t["shift"].data_ptr(), t["mean"].data_ptr(), t["rstd"].data_ptr(), rm.data_ptr(),
+                                     rv.data_ptr(), 0.1, None, nws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append({**{k: v.cpu() for k, v in t.items()}, "rm": rm.cpu(), "rv": rv.cpu()})
+    a = out.float().cpu()
+    a = torch.relu(a) if out_act == "relu" else a
+    mean_ref = a.double().mean(dim=(0, 1, 2))
+    assert rel_err(res[1]["mean"], mean_ref) < 1e-5                        # the pass itself, as a sanity anchor
+    for k in res[0]:
+        assert rel_err(res[0][k], res[1][k]) < 2e-6, k
+    # a launch whose kernel has no statistics epilogue: reported as such, buffer untouched
+    lib.mseg_igemm_set_p8(0)
+    try:
+        marker = torch.full((16,), 7.0, device="cuda")
+        p = eng.MsegIgemm()
+        eng._fill_igemm(p, srcs, wp.Kpad, wp.Npad, N, H, W, H, W, 3, 3, 1, 1, eng.MODE_CONV, Cout, Cout, 0, 0, 0, None,
+                        eng.EPI_PLAIN, 0, eng.MORDER_LINEAR)
+        p.w, p.bias, p.dst0 = wp.bf16().data_ptr(), b.cuda().data_ptr(), plain.data_ptr()
+        p.precision, p.dst_dtype = 1, _lib.ST_BF16 if dst16 else _lib.ST_F32
+        p.stats, p.stats_act = marker.data_ptr(), eng.ACT[out_act]
+        info = _lib.MsegKernelInfo()
+        assert lib.mseg_igemm_query(C.byref(p), C.byref(info)) == 0 and info.stats_rows == 0
+    finally:
+        lib.mseg_igemm_set_p8(1)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,act,per_sample,two_src,want", [
-    (32, 128, 128, 96, 96, "relu", False, False, "igemm_p8_kernel<512, 128, 1>"),    # 32-wide tiles, 512 x 128
-    (20, 256, 256, 80, 80, "relu", True, True, "igemm_p8_kernel<256, 256, 1>"),       # 16-wide tiles, per-sample tables, concat
-    (32, 128, 256, 72, 64, "mish", False, False, "igemm_p8_kernel<256, 256, 2>"),     # tile rows below the image (72 = 9 x 8)
-    (40, 64, 128, 48, 48, "none", False, False, "igemm_p8_kernel<256, 128, 0>"),      # plain operand, 256 x 128 tiles
-    (36, 512, 1024, 32, 32, "elu", False, False, "igemm_p8_kernel<256, 256, 2>"),     # four 256-channel tiles per pixel tile
-    (40, 256, 512, 40, 40, "relu", False, True, "igemm_p8_kernel<256, 256, 1>"),      # image-wide tiles 40 x 6 (240 live rows)
-    (80, 512, 1024, 20, 20, "mish", True, False, "igemm_p8_kernel<256, 256, 2>"),     # image-wide tiles 20 x 12
-    (64, 128, 256, 44, 44, "none", False, False, "igemm_p8_kernel<256, 256, 0>")])    # 44 x 5 (220 live rows), 9 tile rows
+    (32, 128, 128, 96, 96, "relu", False, False, "igemm_p8_kernel<512, 128, 1, false>"),    # 32-wide tiles, 512 x 128
+    (20, 256, 256, 80, 80, "relu", True, True, "igemm_p8_kernel<256, 256, 1, false>"),       # 16-wide tiles, per-sample tables, concat
+    (32, 128, 256, 72, 64, "mish", False, False, "igemm_p8_kernel<256, 256, 2, false>"),     # tile rows below the image (72 = 9 x 8)
+    (40, 64, 128, 48, 48, "none", False, False, "igemm_p8_kernel<256, 128, 0, false>"),      # plain operand, 256 x 128 tiles
+    (36, 512, 1024, 32, 32, "elu", False, False, "igemm_p8_kernel<256, 256, 2, false>"),     # four 256-channel tiles per pixel tile
+    (40, 256, 512, 40, 40, "relu", False, True, "igemm_p8_kernel<256, 256, 1, false>"),      # image-wide tiles 40 x 6 (240 live rows)
+    (80, 512, 1024, 20, 20, "mish", True, False, "igemm_p8_kernel<256, 256, 2, false>"),     # image-wide tiles 20 x 12
+    (64, 128, 256, 44, 44, "none", False, False, "igemm_p8_kernel<256, 256, 0, false>")])    # 44 x 5 (220 live rows), 9 tile rows
 def test_bf16_storage_p8_kernel(eng, N, Cin, Cout, H, W, act, per_sample, two_src, want):
     """Layers with >= 128 output channels on bf16 tensors and at least one tile per CU take the one-workgroup-per-CU kernel
     with DMA-streamed weights (igemm_p8.hip): persistent tile walk (more tiles than CUs, a ragged last round), transposed

@@ -437,13 +437,18 @@ def test_bf16_mode_matches_bf16_oracle(ut, act, norm, filters, size, batch, dev)
         assert _l2_rel(p.grad.cpu(), p16[k].grad) < max(3e-2, 1.5 * noise), k
 
 
+@pytest.mark.parametrize("optimizer", ["fused_adam", "torch_capturable"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_graphed_train_step_equals_eager(precision, dev, request):
+def test_graphed_train_step_equals_eager(precision, optimizer, dev, request):
     """hipGraph replay of the training step (training/graph_step.py): same losses and bit-identical weights as the eager
-    step on the same batches (the kernels and their order are the same; only the launches are pre-recorded)."""
+    step on the same batches (the kernels and their order are the same; only the launches are pre-recorded) — with the
+    default optimizer (FusedAdam: step counter and learning rate on the device, a learning-rate change does not re-record)
+    and with torch's capturable Adam (re-recorded).  An eval forward after the replays must see the trained weights (the
+    packed GEMM operands are refreshed inside the recorded step)."""
     from microbeseg_amd import engine
     from microbeseg_amd.training.graph_step import GraphedTrainStep
     from microbeseg_amd.training.losses import get_loss
+    from microbeseg_amd.training.optim import FusedAdam
     from microbeseg_amd.utils.unets import build_unet
     request.addfinalizer(lambda: engine.set_precision("fp32"))
     engine.set_precision(precision)
@@ -457,7 +462,11 @@ def test_graphed_train_step_equals_eager(precision, dev, request):
     def run(graphed):
         torch.manual_seed(11)
         net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=(64, 128))
-        opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True, capturable=True)
+        if optimizer == "fused_adam":
+            opt = FusedAdam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True)
+        else:
+            opt = torch.optim.Adam(net.parameters(), lr=8e-4, betas=(0.9, 0.999), eps=1e-8, amsgrad=True,
+                                   capturable=True)
         net.train()
 
         def step(x, lb, lc):
@@ -473,19 +482,76 @@ def test_graphed_train_step_equals_eager(precision, dev, request):
             losses.append(float(fn(*b).detach()))
             if i == 4:
                 losses.append(float(fn(*odd).detach()))
-            if i == 5:                                      # a learning-rate step forgets the recording; the very next batch is
-                if graphed:                                 # the short one: it must NOT become the recorded shape
-                    fn.invalidate()
+            if i == 5:                                      # a learning-rate step (ReduceLROnPlateau); the very next batch is
+                recorded = fn.graph if graphed else None    # the short one: it must NOT become the recorded shape
+                if graphed:
+                    fn.set_lr(2e-4)
+                    assert (fn.graph is recorded) == (optimizer == "fused_adam"), "FusedAdam keeps the recorded step"
+                else:
+                    for group in opt.param_groups:
+                        group["lr"] = 2e-4
                 losses.append(float(fn(*odd).detach()))
         if graphed:
             assert fn.graph is not None and fn.shapes[0][0][0] == 4, "the full batch must be the recorded shape again"
-        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
+        if optimizer == "fused_adam":
+            assert all(opt.state[p]["step"] == len(batches) + 2 for p in net.parameters())
+        net.eval()
+        with torch.no_grad():
+            out = [t.detach().clone() for t in net(batches[0][0])]
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, out
 
-    l_e, sd_e = run(False)
-    l_g, sd_g = run(True)
+    l_e, sd_e, out_e = run(False)
+    l_g, sd_g, out_g = run(True)
     assert l_e == l_g
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+    for a, b in zip(out_e, out_g):
+        assert torch.equal(a, b), "eval forward after the replays"
+
+
+def test_conv_epilogue_statistics_in_the_training_step(dev, request):
+    """engine.set_conv_stats(True): BatchNorm statistics of the layers whose convolution kernel can take them in its epilogue
+    (MsegIgemm.stats) instead of a pass over the stored tensor.  The same sums in another order: outputs, running
+    statistics and gradients of a bf16 training step agree with the pass to a few fp32 roundings amplified through bf16
+    storage (a value that moves by one fp32 ulp may round to the neighbouring bf16)."""
+    from microbeseg_amd import engine
+    from microbeseg_amd.utils.unets import build_unet
+    request.addfinalizer(lambda: (engine.set_precision("fp32"), engine.set_conv_stats(False)))
+    engine.set_precision("bf16")
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(16, 1, 128, 128, generator=g) * 2 - 1).to(dev)
+    gb, gc = torch.randn(16, 1, 128, 128, generator=g).to(dev), torch.randn(16, 1, 128, 128, generator=g).to(dev)
+    res = []
+    for fused in (False, True):
+        engine.set_conv_stats(fused)
+        torch.manual_seed(12)
+        net = build_unet("DU", "relu", "conv", "bn", dev, 1, ch_out=1, filters=(64, 128))
+        net.train()
+        taken = []
+        orig = engine.norm_stats
+
+        def spy(node, *a, conv_part=None, **k):
+            taken.append(conv_part is not None)
+            return orig(node, *a, conv_part=conv_part, **k)
+        engine.norm_stats = spy
+        try:
+            border, cell = net(x)
+            ((border * gb).sum() + (cell * gc).sum()).backward()
+        finally:
+            engine.norm_stats = orig
+        assert any(taken) == fused, "the 128-channel layers of this network take the statistics in the epilogue"
+        res.append(([border.detach().cpu(), cell.detach().cpu()],
+                    {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k},
+                    {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert rel_err(b, a) < 2e-2
+    for k in res[0][1]:
+        assert rel_err(res[1][1][k], res[0][1][k]) < 1e-5, k
+    biggest = max(v.double().norm().item() for v in res[0][2].values())
+    for k in res[0][2]:
+        if res[0][2][k].double().norm().item() < 1e-2 * biggest:
+            continue        # e.g. a convolution bias in front of BatchNorm: analytically zero, rounding noise in both runs
+        assert _l2_rel(res[1][2][k], res[0][2][k]) < 2e-2, k
 
 
 def test_eval_tables_follow_training_and_loading(dev):
