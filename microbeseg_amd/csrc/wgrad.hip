@@ -1155,6 +1155,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for MANY splits (few channel tiles: 64 .. 256 channels, 32 .. 512 splits of 75 MB in all): a workgroup
+// owns one (m, tap) and 64 consecutive n — 16 lanes of 4 channels (16-byte loads, 256 contiguous bytes per split) x 16
+// thread groups striding the split range, combined through LDS in fixed order.  The one-tap-per-workgroup grid is 9 x larger
+// than the one above (576 workgroups for a 64 x 64 layer instead of 256 with 64-byte runs), which is what the read
+// bandwidth needs; its output, 4 floats per lane at stride T, is 0.2 % of the traffic.
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const float* __restrict__ ws, float* __restrict__ dst,
+                                                                int splits, int T, int Mch, int Nch, int Nst) {
+  __shared__ float4 red[16][16];
+  const int nl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int nchunks = (Nch + 63) / 64;
+  int idx = blockIdx.x;
+  const int t = idx % T; idx /= T;
+  const int nc = idx % nchunks, m = idx / nchunks;
+  const int n = nc * 64 + nl * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < Nch) {
+    const size_t sstride = (size_t)T * Mch * Nch;
+    const float* base = ws + ((size_t)t * Mch + m) * Nch + n;
+#pragma unroll 4
+    for (int k = kg; k < splits; k += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)k * sstride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[kg][nl] = acc;
+  __syncthreads();
+  if (kg == 0 && n < Nch) {
+    float4 v = red[0][nl];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { const float4 u = red[j][nl]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    float* out = dst + ((size_t)m * Nst + n) * T + t;
+    if (n + 0 < Nst) out[0 * T] = v.x;
+    if (n + 1 < Nst) out[1 * T] = v.y;
+    if (n + 2 < Nst) out[2 * T] = v.z;
+    if (n + 3 < Nst) out[3 * T] = v.w;
+  }
+}
+
 // Which kernel a launch goes to (shared by the split-K plan and the launcher): 2 = halo (pixel blocks), 1 = fast (linear
 // 32-pixel steps), 0 = generic.
 struct WgradSel { int kind, tw_log2, ptr, qtr; bool generic_act, per_sample; };
@@ -1381,7 +1419,12 @@ static int wgrad_dispatch(const MsegWgrad* pp, void* stream) {
   }
   if (p.phase == 1) return MSEG_OK;
   // many splits (few channel tiles: the wide shallow levels) -> 16 thread groups share the split range
-  if (splits >= 32) {
+  if (splits >= 32 && (p.Nch & 3) == 0 && (((uintptr_t)p.ws) & 15) == 0 &&
+      (long long)p.P.C * ((p.Nch + 63) / 64) * T <= 0x7fffffffLL) {
+    const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 63) / 64) * (unsigned)T;
+    MSEG_KL_AUX(wgrad_reduce_many_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
+                       p.P.C, p.Nch, p.Nch_store);
+  } else if (splits >= 32) {
     const unsigned blocks = (unsigned)p.P.C * (unsigned)((p.Nch + 15) / 16);
     MSEG_KL_AUX((wgrad_reduce_kernel<16>), dim3(blocks), dim3(256), 0, st, (const float*)p.ws, p.dst, splits, T,
                        p.P.C, p.Nch, p.Nch_store);
