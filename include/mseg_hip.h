@@ -413,6 +413,12 @@ int mseg_label_boundary(const uint16_t* mask, int N, int H, int W, int mode, uin
 size_t mseg_label_distance_workspace_bytes(int N, int H, int W);
 int mseg_label_distance(const uint16_t* mask, int N, int H, int W, int search_radius, float* cell_out,
                         float* neighbor_out, void* ws, size_t ws_bytes, void* stream);
+/* bottom_hat_closing(label) of train_data_representations.py:40-72 alone: root_out[N][H][W] = raster index (inside its image)
+ * of the first pixel of the gap component a pixel belongs to, -1 outside the gaps (the rank of a root among the distinct
+ * roots of an image + 1 is measure.label's id); corr_out = 0 outside, 1 inside a gap, 0.8 on the 4-neighbour rim of a gap
+ * with minor_axis_length >= 3.  Same workspace as mseg_label_distance.                                                */
+int mseg_label_bottom_hat(const uint16_t* mask, int N, int H, int W, int32_t* root_out, float* corr_out, void* ws,
+                          size_t ws_bytes, void* stream);
 /* j4_label(label, k_neighbors, se_radius) of train_data_representations.py:157-216 (Pena et al. 2020): 0 background,
  * 1 cell, 2 touching (another instance inside the (2k+1)^2 window), 3 gap (bottom-hat with disk(se_radius)); uint8.
  * tmp: device scratch of N*H*W bytes.                                                                                 */

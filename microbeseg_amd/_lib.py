@@ -135,6 +135,7 @@ SIGNATURES = {
     "mseg_label_boundary": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mseg_label_distance_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_label_distance": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "mseg_label_bottom_hat": (_I, [_P, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "mseg_label_cell_distance": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _SZ, _P]),
     "mseg_label_j4": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mseg_label_major_axis_workspace_bytes": (_SZ, [_I]),

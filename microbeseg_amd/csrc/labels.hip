@@ -550,6 +550,71 @@ extern "C" int mseg_label_distance(const uint16_t* mask, int N, int H, int W, in
   return MSEG_OK;
 }
 
+// bottom_hat_closing alone (train_data_representations.py:40-72): the gap components between the per-cell closings and
+// their weights.  root[t] = raster index (inside its image) of the component's first pixel, -1 outside the gaps — ranking the
+// distinct roots gives measure.label's numbering; corr[t] = 0 outside, 1 in a gap, 0.8 on the 4-neighbour rim of a gap whose
+// minor axis length is >= 3.  Same passes as inside mseg_label_distance.
+__global__ void lb_bottom_hat_out_kernel(const int32_t* __restrict__ L, const LbGap* __restrict__ gaps, int N, int H, int W,
+                                         int32_t* __restrict__ root_out, float* __restrict__ corr) {
+  const size_t hw = (size_t)H * W, n = (size_t)N * hw;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = t / hw;
+    const int r = (int)(t - s * hw);
+    const int y = r / W, x = r - y * W;
+    const int32_t* l = L + s * hw;
+    const int root = l[r];
+    float v = 0.f;
+    if (root >= 0) {
+      const LbGap g = gaps[s * hw + root];
+      const double cnt = (double)g.cnt;
+      const double a = (double)(long long)(g.cnt * g.syy - g.sy * g.sy) / (cnt * cnt);
+      const double c = (double)(long long)(g.cnt * g.sxx - g.sx * g.sx) / (cnt * cnt);
+      const double b = (double)((long long)(g.cnt * g.sxy) - (long long)(g.sx * g.sy)) / (cnt * cnt);
+      const double l2 = 0.5 * (a + c) - 0.5 * sqrt(4.0 * b * b + (a - c) * (a - c));
+      const bool wide = 4.0 * sqrt(fmax(l2, 0.0)) >= 3.0;
+      bool rim = false;
+      if (wide) {
+        rim = y == 0 || y == H - 1 || x == 0 || x == W - 1;
+        if (!rim) rim = l[r - 1] != root || l[r + 1] != root || l[r - W] != root || l[r + W] != root;
+      }
+      v = rim ? 0.8f : 1.f;
+    }
+    root_out[t] = root;
+    corr[t] = v;
+  }
+}
+
+extern "C" int mseg_label_bottom_hat(const uint16_t* mask, int N, int H, int W, int32_t* root_out, float* corr_out, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (!mask || !root_out || !corr_out || !ws) return MSEG_EINVAL;
+  const size_t need = mseg_label_distance_workspace_bytes(N, H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const LbLayout l = lb_layout(N, H, W);
+  char* base = (char*)ws;
+  LbGap* gaps = (LbGap*)(base + l.gaps);
+  double* nb = (double*)(base + l.nb);
+  uint8_t* bin = (uint8_t*)(base + l.bin);
+  uint8_t* tmp = (uint8_t*)(base + l.tmp);
+  uint8_t* gap = (uint8_t*)(base + l.gap);
+  int32_t* L = (int32_t*)(base + l.L);
+  const size_t hw = (size_t)H * W, px = (size_t)N * hw;
+  const unsigned nbk = lb_blocks(px);
+  if (hipMemsetAsync(ws, 0, l.zero_bytes, st) != hipSuccess) return MSEG_ELAUNCH;
+  if (hipMemsetAsync(nb, 0, px * sizeof(double), st) != hipSuccess) return MSEG_ELAUNCH;    // no neighbour distances here
+  hipLaunchKernelGGL(lb_close_cells_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, mask, N, H, W, bin);
+  hipLaunchKernelGGL(lb_disk_kernel<false>, dim3(nbk), dim3(LB_BLOCK), 0, st, bin, bin, N, H, W, tmp);
+  hipLaunchKernelGGL(lb_disk_kernel<true>, dim3(nbk), dim3(LB_BLOCK), 0, st, tmp, bin, N, H, W, gap);
+  hipLaunchKernelGGL(lb_ccl_init_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, gap, N, hw, L);
+  hipLaunchKernelGGL(lb_ccl_merge_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, gap, N, H, W, L);
+  hipLaunchKernelGGL(lb_ccl_flatten_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, N, hw, L);
+  hipLaunchKernelGGL(lb_gap_props_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, L, nb, N, H, W, gaps);
+  hipLaunchKernelGGL(lb_bottom_hat_out_kernel, dim3(nbk), dim3(LB_BLOCK), 0, st, L, gaps, N, H, W, root_out, corr_out);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
 // ---- j4_label (train_data_representations.py:157-188; Pena et al., ISBI 2020): background / cell / touching / gap -------------
 // gap = bottom-hat of the binary mask with disk(se_radius) (closing ^ mask; scipy's border_value 0), touching = cell pixels
 // whose (2k+1)^2 window holds more than one instance id (compute_neighbor_instances :191-216).  0 background, 1 cell,

@@ -94,6 +94,40 @@ def distance_label(label, search_radius):
     return cell[0], nb[0]
 
 
+def bottom_hat_closing(label):
+    """ Bottom-hat-transform based grayscale closing (reference :40-72).
+
+    :param label: Intensity coded label image.
+    :return: closed label (only closed regions, numbered like ``measure.label``), closed label (only closed regions,
+        1.0, or 0.8 on the rim of gaps with a minor axis length of at least 3), float32.
+    """
+    if not torch.cuda.is_available():
+        raise RuntimeError("microbeseg_amd label creation needs the MI355X HIP path (no CPU fallback)")
+    lib = _lib.load()
+    a = np.ascontiguousarray(label)
+    if a.ndim != 2:
+        raise RuntimeError("expected a 2-D intensity-coded instance mask")
+    if a.min(initial=0) < 0 or a.max(initial=0) > 65535:
+        raise RuntimeError("instance ids must fit uint16")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H, W = a.shape
+    m = torch.from_numpy(a.astype(np.uint16).view(np.int16)).to(dev)
+    root = torch.empty((H, W), dtype=torch.int32, device=dev)
+    corr = torch.empty((H, W), dtype=torch.float32, device=dev)
+    need = lib.mseg_label_distance_workspace_bytes(1, H, W)
+    if need == 0:
+        raise RuntimeError("unsupported mask shape")
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mseg_label_bottom_hat(m.data_ptr(), 1, H, W, root.data_ptr(), corr.data_ptr(), ws.data_ptr(), need,
+                                         torch.cuda.current_stream().cuda_stream), "label_bottom_hat")
+    # measure.label numbers the components by their first pixel in raster order = the rank of the component's root
+    roots, inverse = torch.unique(root, sorted=True, return_inverse=True)      # roots[0] == -1 iff there is background
+    ids = inverse
+    if roots.numel() and roots[0].item() >= 0:
+        ids = inverse + 1                                                      # (no pixel outside the gaps at all)
+    return ids.to(torch.int64).cpu().numpy(), corr.cpu().numpy()
+
+
 def cell_distance_label(label, search_radius, apply_clipping=False, clip_val=5):
     """ Cell distance label creation (Euclidean distance), reference :219-258: the per-cell normalised distance
     transform alone, or (apply_clipping) min(distance, clip_val) / clip_val.  float32 (H, W). """

@@ -90,6 +90,22 @@ def test_distance_golden_covers_branches():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("i", DCASES)
+def test_bottom_hat_closing_hip_matches_reference(i):
+    """bottom_hat_closing (reference :40-72) as its own entry point: the reference's closed / corr images of the golden masks
+    (committed fixtures) and the oracle's component numbering (scipy / measure.label order), bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from microbeseg_amd.training import train_data_representations as T
+    closed, corr = T.bottom_hat_closing(GD[f"m{i}"])
+    assert corr.dtype == np.float32
+    assert np.array_equal(closed, GD[f"closed{i}"])            # the reference's measure.label ids
+    assert np.array_equal(corr, GD[f"corr{i}"])
+    comp, weight = labels_ref.bottom_hat_closing(GD[f"m{i}"])
+    assert np.array_equal(closed, comp) and np.array_equal(corr, weight)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", DCASES)
 def test_distance_hip_matches_reference(i):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
