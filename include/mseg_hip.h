@@ -225,6 +225,11 @@ size_t mseg_norm_workspace_bytes(int N, int HW, int C);
  * reduction / finalize launches (same results, bit for bit).  Default 0 (measured faster at batch 32); MSEG_NORM_TAILS in
  * the environment sets it for a process. */
 int mseg_norm_set_tails(int on);
+/* 1 (default): the small launch that reduces a pass's partial sums over the chunks also writes the per-channel results
+ * (BatchNorm tables and running statistics, k1 / k2 / k3 + dgamma / dbeta, bias gradients) when there are <= 256 channels —
+ * its last workgroup to arrive does what the finalize / column-sum launch did, same order, same bits; 0: always the
+ * separate launch.  MSEG_NORM_FINISH in the environment sets it for a process. */
+int mseg_norm_set_finish(int on);
 /* st: MSEG_ST_F32 / MSEG_ST_BF16 = storage of the activation tensors of the call (z, act_out; gy, dz, act_in below).  With
  * bf16 storage a thread owns 8 channels (C % 8 == 0) and the statistics are those of the values as stored.           */
 int mseg_norm_stats(const void* z, int N, int HW, int C, int st, int act, int norm, const float* gamma,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "mseg_pack_weights_multi": (_I, [_P, _I, C.c_uint, _P]),
     "mseg_norm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "mseg_norm_set_tails": (_I, [_I]),
+    "mseg_norm_set_finish": (_I, [_I]),
     "mseg_norm_stats_from_conv": (_I, [_P, _I, _I, C.c_longlong, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "mseg_norm_stats": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mseg_activation": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -24,14 +24,16 @@ static NormGeom norm_geom(int N, int HW, int C, int vec = 4) {
   // A workgroup = 256 threads = rpi row slots x cw channel groups (a thread owns V channels of its rows), one per
   // (chunk of rows, sample, slice of <= 16 channel groups).  Slicing the channels keeps >= 16 row slots per workgroup at
   // any channel count and gives the reductions over chunks / samples of a slice to the LAST workgroup of that slice (the
-  // in-kernel tails below) in small pieces.  Aim at 2048 workgroups (eight per CU: all resident at once, each a long streaming loop — and half the
-  // partial sums of the 4096 of earlier rounds for the tails to read) with at least 8 rows per row slot.
+  // in-kernel tails below) in small pieces.  Aim at 1024 workgroups (four per CU: all resident at once, each a long
+  // streaming loop; measured round 3 against 2048 and 4096: the epilogue and the partial sums weigh less, -0.6 % per bf16
+  // step) with at least 8 rows per row slot.
   const int C4 = C / vec;
   g.cw = C4 < 16 ? (C4 > 0 ? C4 : 1) : 16;
   g.slices = (C4 + g.cw - 1) / g.cw;
   const int rpi = 256 / g.cw;
   const int min_rows = 8 * rpi;
-  int want = (2048 + N * g.slices - 1) / (N * g.slices > 0 ? N * g.slices : 1);
+  const int target = 1024;
+  int want = (target + N * g.slices - 1) / (N * g.slices > 0 ? N * g.slices : 1);
   int chunks = HW / min_rows;
   if (chunks > want) chunks = want;
   if (chunks < 1) chunks = 1;
@@ -202,6 +204,11 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
     for (int r = row_begin + r0; r < row_end; r += rpi * U) {
       NormVec<S16> zv[U], gv[U], av[U];
       bool ok[U];
+      // the sums of one trip (<= U values per channel) are taken in fp32 and join the fp64 running sums once per trip: the
+      // conversions and fp64 additions per ELEMENT were a third of the pass's vector instructions
+      float p0[V], p1[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) { p0[j] = 0.f; p1[j] = 0.f; }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ru = r + u * rpi;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
           for (int j = 0; j < V; ++j) d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * d[j];
           NormVec<S16>::put(dz, off, d);
 #pragma unroll
-          for (int j = 0; j < V; ++j) s0[j] += d[j];
+          for (int j = 0; j < V; ++j) p0[j] += d[j];
           continue;
         }
         if (MODE == 1 && AIO) av[u].get(a4);
@@ -248,13 +255,13 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
         if (MODE == 3) continue;
         if (MODE == 0) {
 #pragma unroll
-          for (int j = 0; j < V; ++j) { s0[j] += a4[j]; s1[j] += (double)a4[j] * a4[j]; }
+          for (int j = 0; j < V; ++j) { p0[j] += a4[j]; p1[j] = fmaf(a4[j], a4[j], p1[j]); }
         } else {
           float gf[V];
           gv[u].get(gf);
           if (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) { s0[j] += gf[j]; s1[j] += (double)gf[j] * a4[j]; }
+            for (int j = 0; j < V; ++j) { p0[j] += gf[j]; p1[j] = fmaf(gf[j], a4[j], p1[j]); }
           } else {
             float d[V];
 #pragma unroll
@@ -262,30 +269,70 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
               d[j] = (a1[j] * gf[j] + a2[j] * a4[j] + a3[j]) * (S16 ? act_bwd_fast(zf[j], act) : act_bwd(zf[j], act));
             NormVec<S16>::put(dz, off, d);      // d now holds dz as stored
 #pragma unroll
-            for (int j = 0; j < V; ++j) s0[j] += d[j];
+            for (int j = 0; j < V; ++j) p0[j] += d[j];
           }
         }
+      }
+      if (MODE != 3) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s0[j] += (double)p0[j]; if (NS == 2) s1[j] += (double)p1[j]; }
       }
     }
   }
   if (MODE == 3) return;
-#pragma unroll
-  for (int j = 0; j < V; ++j) {
-    red[tid * 2 * V + j] = s0[j];
-    red[tid * 2 * V + V + j] = s1[j];
-  }
-  __syncthreads();
-  if (r0 == 0 && c4 < C4) {
-    double t0[V], t1[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
-    for (int k = 0; k < rpi; ++k) {
+  double t0[V], t1[V];
+  const bool fold = (CW & (CW - 1)) == 0;               // channel groups per row slot a power of two (<= 16): the common case
+  if (fold) {
+    // The row slots of a wave that hold the same channels are the lanes l, l ^ CW, l ^ 2 CW, ...: an xor butterfly leaves
+    // their sum in every lane (fixed tree), the four waves meet in LDS — 64 values per finishing thread instead of the
+    // 2 x 16 x 32 serial LDS reads below, which were ~6 us of every pass.
+    for (int m = CW; m < 64; m <<= 1) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        t0[j] += red[(k * CW + cq) * 2 * V + j];
-        t1[j] += red[(k * CW + cq) * 2 * V + V + j];
+        s0[j] += __shfl_xor(s0[j], m, 64);
+        if (NS == 2) s1[j] += __shfl_xor(s1[j], m, 64);
       }
     }
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < CW) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        red[(wv * CW + lane) * 2 * V + j] = s0[j];
+        red[(wv * CW + lane) * 2 * V + V + j] = s1[j];
+      }
+    }
+    __syncthreads();
+    if (tid < CW) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { t0[j] = red[tid * 2 * V + j]; t1[j] = red[tid * 2 * V + V + j]; }
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          t0[j] += red[(w * CW + tid) * 2 * V + j];
+          t1[j] += red[(w * CW + tid) * 2 * V + V + j];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      red[tid * 2 * V + j] = s0[j];
+      red[tid * 2 * V + V + j] = s1[j];
+    }
+    __syncthreads();
+    if (r0 == 0 && c4 < C4) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { t0[j] = 0.0; t1[j] = 0.0; }
+      for (int k = 0; k < rpi; ++k) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          t0[j] += red[(k * CW + cq) * 2 * V + j];
+          t1[j] += red[(k * CW + cq) * 2 * V + V + j];
+        }
+      }
+    }
+  }
+  if (r0 == 0 && c4 < C4) {
     if (t.kind == NORM_TAIL_NONE) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -416,9 +463,8 @@ __global__ __launch_bounds__(256) void norm_pass_kernel(const void* __restrict__
 }
 
 // nc[s][n][c] = sum over chunks of part[n][chunk][s][c]; 32 outputs x 8 chunk groups per workgroup, fixed order
-__global__ __launch_bounds__(256) void norm_reduce_chunks_kernel(const double* __restrict__ part, double* __restrict__ nc,
-                                                                 NormGeom g, int ns) {
-  __shared__ double red[8][32];
+__device__ __forceinline__ void norm_reduce_chunks_body(const double* __restrict__ part, double* __restrict__ nc,
+                                                        const NormGeom& g, int ns, bool handoff, double (*red)[32]) {
   const int o = threadIdx.x & 31, kg = threadIdx.x >> 5;
   const int total = ns * g.N * g.C;
   for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
@@ -437,23 +483,33 @@ __global__ __launch_bounds__(256) void norm_reduce_chunks_kernel(const double* _
       double t = 0.0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) t += red[j][o];
-      nc[((size_t)sidx * g.N + n) * g.C + c] = t;
+      double* dst = nc + ((size_t)sidx * g.N + n) * g.C + c;
+      if (handoff) norm_st_sc1(dst, t);                // read by another workgroup of this launch: write-through
+      else *dst = t;
     }
     __syncthreads();
   }
 }
 
+__global__ __launch_bounds__(256) void norm_reduce_chunks_kernel(const double* __restrict__ part, double* __restrict__ nc,
+                                                                 NormGeom g, int ns) {
+  __shared__ double red[8][32];
+  norm_reduce_chunks_body(part, nc, g, ns, false, red);
+}
+
 // forward finalize: statistics -> scale/shift tables (+ saved mean/rstd, BN running stats)
-__global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                         float* __restrict__ scale, float* __restrict__ shift,
-                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         float momentum, double count) {
+// (`first`, `stride`: the calling thread's index and the thread count of the launch — or of ONE workgroup, when the last
+// workgroup of the reduction launch finishes the job itself, norm_reduce_finish_kernel)
+__device__ __forceinline__ void norm_fwd_finalize_body(const double* __restrict__ nc, const NormGeom& g, int norm,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                       float momentum, double count, int first, int stride) {
   const double* S = nc;
   const double* Q = nc + (size_t)g.N * g.C;
   if (norm == MSEG_NORM_BN) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+    for (int c = first; c < g.C; c += stride) {
       double s = 0.0, q = 0.0;
       // (unrolled: the loads of 8 samples are in flight together; rolled, this tiny kernel was 32 dependent memory round
       // trips = 11 us, 114 such launches per step; the order of the additions is unchanged)
@@ -481,7 +537,7 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   const int groups = (norm == MSEG_NORM_GN) ? 8 : g.C;
   const int cg = g.C / groups;
   const int total = g.N * g.C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < total; i += stride) {
     const int c = i % g.C, n = i / g.C;
     const int grp = c / cg;
     double s = 0.0, q = 0.0;
@@ -505,16 +561,27 @@ __global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   }
 }
 
+__global__ void norm_fwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum, double count) {
+  norm_fwd_finalize_body(nc, g, norm, gamma, beta, eps, scale, shift, mean_out, rstd_out, running_mean, running_var, momentum,
+                         count, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // backward finalize: per-(n,c) sums of gy and gy*a -> k1,k2,k3 tables, dgamma, dbeta
-__global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
-                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                         const float* __restrict__ rstd, float* __restrict__ k1,
-                                         float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta) {
+__device__ __forceinline__ void norm_bwd_finalize_body(const double* __restrict__ nc, const NormGeom& g, int norm,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ k1,
+                                                       float* __restrict__ k2, float* __restrict__ k3,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int first,
+                                                       int stride) {
   const double* S1 = nc;                        // sum gy
   const double* S2 = nc + (size_t)g.N * g.C;    // sum gy*a
   if (norm == MSEG_NORM_BN) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+    for (int c = first; c < g.C; c += stride) {
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
       for (int n = 0; n < g.N; ++n) { s1 += S1[(size_t)n * g.C + c]; s2 += S2[(size_t)n * g.C + c]; }
@@ -533,7 +600,7 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   const int groups = (norm == MSEG_NORM_GN) ? 8 : g.C;
   const int cg = g.C / groups;
   const int total = g.N * g.C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < total; i += stride) {
     const int c = i % g.C, n = i / g.C;
     const int grp = c / cg;
     const double mu = mean[n * groups + grp], r = rstd[n * groups + grp];
@@ -554,7 +621,7 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   }
   if (norm == MSEG_NORM_GN && dgamma) {
     // dgamma_c = sum_n rstd*(S2 - mean*S1), dbeta_c = sum_n S1   (one thread per channel, fixed order)
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+    for (int c = first; c < g.C; c += stride) {
       const int grp = c / cg;
       double dg = 0.0, db = 0.0;
       for (int n = 0; n < g.N; ++n) {
@@ -569,14 +636,47 @@ __global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom
   }
 }
 
+__global__ void norm_bwd_finalize_kernel(const double* __restrict__ nc, NormGeom g, int norm,
+                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, float* __restrict__ k1,
+                                         float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta) {
+  norm_bwd_finalize_body(nc, g, norm, gamma, mean, rstd, k1, k2, k3, dgamma, dbeta, blockIdx.x * blockDim.x + threadIdx.x,
+                         gridDim.x * blockDim.x);
+}
+
 // dbias[c] = sum_n nc[0][n][c]
-__global__ void norm_colsum_kernel(const double* __restrict__ nc, NormGeom g, float* __restrict__ out) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < g.C; c += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void norm_colsum_body(const double* __restrict__ nc, const NormGeom& g, float* __restrict__ out,
+                                                 int first, int stride) {
+  for (int c = first; c < g.C; c += stride) {
     double s = 0.0;
 #pragma unroll 8
     for (int n = 0; n < g.N; ++n) s += nc[(size_t)n * g.C + c];
     out[c] = (float)s;
   }
+}
+__global__ void norm_colsum_kernel(const double* __restrict__ nc, NormGeom g, float* __restrict__ out) {
+  norm_colsum_body(nc, g, out, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The reduction over the chunks AND what used to be the launch after it (finalize / column sums), for per-channel results
+// of <= 256 channels (BatchNorm, bias gradients: one channel per thread of ONE workgroup): the last workgroup of the
+// reduction to arrive does it — same code, same order, same results as the two launches, one ~5 us launch less per pass.
+// Unlike the in-kernel tails of the big pass (slower: every one of its 1024 workgroups pays for the hand-off) the hand-off
+// here is between the few workgroups of a 5-us kernel.  Counter: the LAST slot of the workspace's counter block.
+__global__ __launch_bounds__(256) void norm_reduce_finish_kernel(const double* __restrict__ part, double* __restrict__ nc,
+                                                                 NormGeom g, int ns, const NormTail t) {
+  __shared__ double red[8][32];
+  __shared__ int s_flag;
+  norm_reduce_chunks_body(part, nc, g, ns, true, red);
+  if (!norm_arrive(t.ctr + NORM_CTR_MAX - 1, gridDim.x, threadIdx.x, &s_flag)) return;
+  if (t.kind == NORM_TAIL_BN_FWD)
+    norm_fwd_finalize_body(nc, g, MSEG_NORM_BN, t.gamma, t.beta, t.eps, t.scale, t.shift, t.mean_out, t.rstd_out, t.running_mean,
+                           t.running_var, t.momentum, 0.0, threadIdx.x, 256);
+  else if (t.kind == NORM_TAIL_BN_BWD)
+    norm_bwd_finalize_body(nc, g, MSEG_NORM_BN, t.gamma, t.mean, t.rstd, t.k1, t.k2, t.k3, t.dgamma, t.dbeta, threadIdx.x, 256);
+  else
+    norm_colsum_body(nc, g, t.colsum, threadIdx.x, 256);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -610,6 +710,20 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
     else NORM_PASS_A(MODE_, false, __VA_ARGS__);                                                                     \
   } while (0)
 
+// 1 (default): the reduction over the chunks also writes the per-channel results where one workgroup can (BatchNorm tables,
+// bias gradients, <= 256 channels) instead of leaving them to a further launch; MSEG_NORM_FINISH=0: always two launches
+static int g_norm_finish = -1;
+extern "C" int mseg_norm_set_finish(int on) {
+  g_norm_finish = on ? 1 : 0;
+  return MSEG_OK;
+}
+static bool norm_finish_fits(int C) {
+  if (g_norm_finish < 0) {
+    const char* e = getenv("MSEG_NORM_FINISH");
+    g_norm_finish = e ? (atoi(e) != 0) : 1;
+  }
+  return g_norm_finish && C <= 256;
+}
 static int g_norm_tails = -1;          // -1: not set yet (MSEG_NORM_TAILS in the environment, else the default below)
 // Test / ablation hook: 1 = the last workgroups of a pass finish the reductions in the kernel, 0 = every pass is followed by
 // the separate reduction / finalize launches (same results, bit for bit)
@@ -648,6 +762,13 @@ extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int
             (const float*)nullptr, 0, g, act, part, aio_, t);
   MSEG_LAUNCH_CHECK();
   if (t.kind != NORM_TAIL_NONE) return MSEG_OK;
+  if (norm == MSEG_NORM_BN && norm_finish_fits(C)) {
+    t.kind = NORM_TAIL_BN_FWD;
+    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
+                       (const double*)part, nc, g, 2, t);
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
   hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                      (const double*)part, nc, g, 2);
   MSEG_LAUNCH_CHECK();
@@ -753,7 +874,13 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   NORM_PASS(1, const_cast<void*>(act_in), z, gy, (void*)nullptr, (const float*)nullptr, (const float*)nullptr,
             (const float*)nullptr, 0, g, act, part, aio_, t);
   MSEG_LAUNCH_CHECK();
-  if (t.kind == NORM_TAIL_NONE) {
+  if (t.kind == NORM_TAIL_NONE && norm == MSEG_NORM_BN && norm_finish_fits(C)) {
+    NormTail tf = t;
+    tf.kind = NORM_TAIL_BN_BWD;
+    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
+                       (const double*)part, nc, g, 2, tf);
+    MSEG_LAUNCH_CHECK();
+  } else if (t.kind == NORM_TAIL_NONE) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
                        (const double*)part, nc, g, 2);
     MSEG_LAUNCH_CHECK();
@@ -768,7 +895,13 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   NORM_PASS(2, const_cast<void*>(act_in), z, gy, dz, (const float*)k1, (const float*)k2, (const float*)k3, kss, g, act,
             part2, aio_, t2);
   MSEG_LAUNCH_CHECK();
-  if (dbias && t2.kind == NORM_TAIL_NONE) {
+  if (dbias && t2.kind == NORM_TAIL_NONE && norm_finish_fits(C)) {
+    NormTail tf = t2;
+    tf.kind = NORM_TAIL_COLSUM;
+    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,
+                       (const double*)part2, nc, g, 1, tf);
+    MSEG_LAUNCH_CHECK();
+  } else if (dbias && t2.kind == NORM_TAIL_NONE) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,
                        (const double*)part2, nc, g, 1);
     MSEG_LAUNCH_CHECK();
