@@ -360,6 +360,11 @@ size_t mseg_postproc_workspace_bytes(int H, int W);
  * 0 = probe global memory instead).  Negative values restore the defaults.  Results never depend on these values; the
  * tests use them to drive the spill and global-probe paths.  Process-wide. */
 int mseg_postproc_tuning(int heap_rows, int tile_small_px, int tile_large_px);
+/* Test / ablation hook: the marker phase of a constant-image flood (the boundary method: watershed(image = mask), every key
+ * ties) — 1 (default) = the closed form of what the reference's binary heap does with equal keys (markers surface in the
+ * preorder of the implicit heap tree, array slots turn into pushed entries in its postorder, a marker still in the array's
+ * last slot jumps the queue; 64 pops per step), 0 = the replay of the heap itself.  Same pop and push order, same labels. */
+int mseg_postproc_set_const_stream(int on);
 int mseg_distance_postprocess(const float* border, const float* cell, int H, int W, float th_cell, float th_seed,
                               int col_major_ids, uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev,
                               void* ws, size_t ws_bytes, void* stream);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mseg_ranger_step_multi": (_I, [_P, _I, _D, _D, _D, _D, _P]),
     "mseg_postproc_workspace_bytes": (_SZ, [_I, _I]),
     "mseg_postproc_tuning": (_I, [_I, _I, _I]),
+    "mseg_postproc_set_const_stream": (_I, [_I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_distance_postprocess_sweep": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P, _P,

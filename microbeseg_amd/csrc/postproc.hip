@@ -25,6 +25,7 @@
 
 // counters (int32 slots in workspace)
 enum { C_NCOMP = 0, C_TOTAL = 1, C_KEPT = 2, C_TAINT = 3, C_NMCOMP = 4, C_SERIAL = 5, C_SCRATCH = 6, C_CONST_M = 7,
+       C_CONST_STREAM = 8,   // 1: every marker key is equal (constant image): the marker phase runs as pp_flood_const_stream
        C_CONST_Q = 12, C_WORK_S = 16, C_WORK_L = 18, C_PART = 20, C_COUNT = 84 };   // C_WORK_*: two slots each; C_PART: 2 x 32
 
 struct PPWs {
@@ -942,6 +943,9 @@ __device__ __forceinline__ void ppl_pop(PPHeapL& h, unsigned long long& tk, uint
 }
 
 #define PPC_THREADS 1024
+// test / ablation hook (mseg_postproc_tuning): 0 = the marker phase of a constant-image flood replays the textbook heap
+// (pp_flood_const_serial_kernel) instead of the closed form (pp_flood_const_stream_kernel); same labels either way
+static int g_ppc_stream = 1;
 __device__ __forceinline__ int ppc_block_scan(int* sh, int tid, int v, int* total) {   // exclusive prefix of v over lanes
   sh[tid] = v;
   __syncthreads();
@@ -957,31 +961,25 @@ __device__ __forceinline__ int ppc_block_scan(int* sh, int tid, int v, int* tota
   return incl - v;
 }
 
-// kernel 1/3: labels start as the markers; marker pixels listed in raster order
-__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_init_kernel(
-    const int32_t* __restrict__ markers, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
-    int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
-  __shared__ int sh_scan[PPC_THREADS];
-  if (!counters[C_SERIAL]) return;                       // uniform for the whole workgroup
-  const size_t n = (size_t)H * W;
-  const int tid = threadIdx.x;
-  // labels start as the markers; marker pixels are listed in raster order at the END of the queue buffer (the queue
-  // itself never holds a marker, so it stays below n - M)
-  const size_t chunk = (n + PPC_THREADS - 1) / PPC_THREADS;
-  const size_t c0 = (size_t)tid * chunk, c1 = (c0 + chunk < n) ? c0 + chunk : n;
-  int mine = 0;
-  for (size_t i = c0; i < c1; ++i) {
-    const int m = markers[i];
-    out[i] = m;
-    claim[i] = 0xffffffffu;
-    mine += (m != 0);
-  }
-  int M = 0;
-  int moff = ppc_block_scan(sh_scan, tid, mine, &M);
-  uint32_t* mlist = queue + (n - (size_t)M);
-  for (size_t i = c0; i < c1; ++i)
-    if (markers[i] != 0) mlist[moff++] = (uint32_t)i;
-  if (tid == 0) counters[C_CONST_M] = M;
+// kernel 1/3: labels start as the markers; marker pixels listed in raster order at the END of the queue buffer (the queue
+// itself never holds a marker, so it stays below n - M).  Three small launches over all pixels: flags, their prefix sum
+// (pp_exclusive_scan, total = M), the list.  (One 1024-thread workgroup walking the 4 M pixels of a 2048^2 frame took 6.8 ms.)
+__global__ void pp_flood_const_flag_kernel(const int32_t* __restrict__ markers, size_t n, int32_t* __restrict__ flag,
+                                           uint32_t* __restrict__ claim, int32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int m = markers[i];
+  out[i] = m;
+  claim[i] = 0xffffffffu;
+  flag[i] = m != 0;
+}
+__global__ void pp_flood_const_list_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ scan, size_t n,
+                                           uint32_t* __restrict__ queue, int32_t* __restrict__ counters, int stream_mode) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) counters[C_CONST_STREAM] = stream_mode ? 1 : 0;
+  if (i >= n || !flag[i]) return;
+  const size_t M = (size_t)counters[C_CONST_M];
+  queue[n - M + (size_t)scan[i]] = (uint32_t)i;
 }
 
 // kernel 2/3: the age-0 markers through the reference heap — one wavefront.
@@ -1000,7 +998,7 @@ __global__ __launch_bounds__(64) void pp_flood_const_serial_kernel(
   __shared__ uint32_t sh_hidx[PPL_TOP];
   __shared__ int sh_n, sh_qn, sh_mleft;
   __shared__ unsigned sh_age;
-  if (!counters[C_SERIAL]) return;
+  if (!counters[C_SERIAL] || counters[C_CONST_STREAM]) return;       // (constant image: pp_flood_const_stream_kernel did it)
   const size_t n = (size_t)H * W;
   const int lane = threadIdx.x;
   const int M = counters[C_CONST_M];
@@ -1090,6 +1088,304 @@ __global__ __launch_bounds__(64) void pp_flood_const_serial_kernel(
     counters[C_CONST_Q] = sh_qn;
     counters[C_SCRATCH] = 1;                             // status bit 0: the exact serial phase was used
   }
+#undef PPC_LD
+}
+
+// ---- the marker phase WITHOUT the heap (round 3) ------------------------------------------------------------------------------
+// On a constant image every key ties on the value and all M markers carry age 0.  What the textbook heap then does has a
+// closed form (derived from heap_push / heap_pop of the reference, checked against it pop for pop — tools/flood_stream_model.py):
+//   * the heap array starts as the markers in raster order (equal keys are never swapped on push), i.e. an implicit complete
+//     binary tree over positions 0 .. M-1; pushed entries (age > 0) are larger than every marker, so all M markers pop
+//     before any of them, and a pushed entry never sits above a marker;
+//   * a pop moves the array's LAST entry to the root.  If that entry is a pushed one it sinks to the bottom along
+//     "left child if it holds a marker, else right child if it holds a marker" and every marker on the path moves up one
+//     level: the markers therefore surface in the PREORDER of the tree, and the positions turn into pushed entries in its
+//     POSTORDER (a position converts once neither child holds a marker);
+//   * if the last entry is a marker still in its original place (the array has shrunk back into the original region, the
+//     position has not converted yet) it ties with the root's children, stays at the root and is the NEXT pop: it jumps the
+//     queue and leaves the tree (always the tree's last leaf).
+// So with count = heap size, zn = size of the original region still intact, cursor = postorder conversions done:
+//   pop: output the root's marker; count -= 1; tail = count;
+//        tail >= zn                  -> a pushed entry sinks: cursor advances over the next position < zn, next = preorder-next;
+//        tail == zn-1, converted     -> the same, zn = tail;           (post_rank[tail] < cursor)
+//        tail == zn-1, still marker  -> zn = tail, the marker at `tail` jumps: next = it, and the preorder skips it later;
+//        then the popped marker's free neighbours are labelled and pushed (count += k), ages in push order.
+// O(1) per pop instead of a ~18-level sift, and — because both candidate streams are known in advance — 64 pops per
+// window: lanes fetch the next 64 preorder and 64 tail candidates with their free neighbours, a wave-uniform (scalar) loop
+// runs the little automaton above over them, the lanes then claim their pops' neighbours (atomicMin of pop index * 4 +
+// slot) and the window is cut before the first pop that lost a neighbour to an earlier pop of the same window (its push
+// count was overestimated); everything before it is committed, the rest redone.  Bit-identical pop and push order.
+
+// positions -> preorder / postorder ranks of the implicit complete tree of M nodes
+__device__ __forceinline__ unsigned ppc_subtree_size(unsigned v, unsigned M) {
+  unsigned long long lo = v, cnt = 1, size = 0;
+  while (lo < M) {
+    size += (lo + cnt <= M) ? cnt : (M - lo);
+    lo = 2 * lo + 1;
+    cnt *= 2;
+  }
+  return (unsigned)size;
+}
+
+// per marker position p (heap array index): preorder rank r of p; PE[r] = pixel, PPOS[r] = p, PFL[r] = free-neighbour mask
+// of the pixel at the start (bits 0-3: up, left, right, down; bit 31 is set later when the marker jumps the queue);
+// TPK[p] = r << 4 | the same mask; MPOS[pixel] = p.  The masks are kept CURRENT: whoever labels a pixel clears its bit in
+// the masks of all marker neighbours (a few thousand pushes per frame), so a window reads what a pop will push instead of
+// polling the labels of four neighbours per candidate (a second memory round trip per window).
+__global__ void pp_flood_const_orders_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask,
+                                             const int32_t* __restrict__ out, const uint32_t* __restrict__ queue, int H, int W,
+                                             uint32_t* __restrict__ PE, uint32_t* __restrict__ PPOS,
+                                             uint32_t* __restrict__ PFL, uint32_t* __restrict__ TPK,
+                                             uint32_t* __restrict__ MPOS, int32_t* __restrict__ counters) {
+  if (!counters[C_SERIAL]) return;
+  const size_t n = (size_t)H * W;
+  const unsigned M = (unsigned)counters[C_CONST_M];
+  const uint32_t* mlist = queue + (n - (size_t)M);
+  const float v0 = M ? img[mlist[0]] : 0.f;
+  bool equal = true;
+  for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < M; p += gridDim.x * blockDim.x) {
+    const uint32_t e = mlist[p];
+    equal &= (img[e] == v0);
+    unsigned pre = 0;
+    for (unsigned v = p; v > 0; v = (v - 1) >> 1) {
+      pre += 1u;
+      if ((v & 1u) == 0u) pre += ppc_subtree_size(v - 1, M);    // right child: the whole left sibling subtree comes before
+    }
+    const int y = (int)(e / (unsigned)W), x = (int)(e - (unsigned)y * W);
+    unsigned f0 = 0;
+    if (y > 0 && mask[e - W] && out[e - W] == 0) f0 |= 1u;
+    if (x > 0 && mask[e - 1] && out[e - 1] == 0) f0 |= 2u;
+    if (x + 1 < W && mask[e + 1] && out[e + 1] == 0) f0 |= 4u;
+    if (y + 1 < H && mask[e + W] && out[e + W] == 0) f0 |= 8u;
+    PE[pre] = e; PPOS[pre] = p; PFL[pre] = f0;
+    TPK[p] = (pre << 4) | f0;
+    MPOS[e] = p;                                       // marker pixel -> its position
+  }
+  if (!equal) atomicAnd((unsigned*)&counters[C_CONST_STREAM], 0u);
+}
+
+// "position q comes strictly before position c in the postorder of the implicit tree" from the two root paths (index + 1 in
+// binary = 1, then left / right bits): a descendant comes before its ancestor; otherwise the one whose ancestor at the common
+// depth lies further left.  c < 0: the cursor is past the root — everything is before it.
+__device__ __forceinline__ bool ppc_post_before(int q, int c) {
+  if (c < 0) return true;
+  const unsigned a = (unsigned)q + 1u, b = (unsigned)c + 1u;
+  const int da = 31 - __clz(a), db = 31 - __clz(b);
+  const int d = da < db ? da : db;
+  const unsigned aa = a >> (da - d), bb = b >> (db - d);
+  if (aa == bb) return da > db;
+  return aa < bb;
+}
+// postorder successor of c in the tree of the first zn positions (-1 after the root)
+__device__ __forceinline__ int ppc_post_next(int c, int zn) {
+  if (c <= 0) return -1;
+  if ((c & 1) && c + 1 < zn) {
+    int v = c + 1;
+    while (2 * v + 1 < zn) v = 2 * v + 1;
+    return v;
+  }
+  return (c - 1) >> 1;
+}
+
+#define PPS_W 64
+// lane `lane` of `old` replaced by the wave-uniform `val`
+__device__ __forceinline__ int pps_writelane(int val, int lane, int old) {
+  return (int)(threadIdx.x & 63u) == lane ? val : old;
+}
+__global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
+    const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
+    const uint32_t* __restrict__ PE, const uint32_t* __restrict__ PPOS, uint32_t* __restrict__ PFL,
+    uint32_t* __restrict__ TPK, const uint32_t* __restrict__ MPOS, const int32_t* __restrict__ isMarker,
+    int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+  if (!counters[C_SERIAL] || !counters[C_CONST_STREAM]) return;
+  const size_t n = (size_t)H * W;
+  const int lane = threadIdx.x;
+  const int M = counters[C_CONST_M];
+  const uint32_t* mlist = queue + (n - (size_t)M);
+#define PPC_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RL(v, i) __builtin_amdgcn_readlane((int)(v), (i))
+  auto nbr = [&](uint32_t e, int s) -> uint32_t { return s == 0 ? e - W : s == 1 ? e - 1 : s == 2 ? e + 1 : e + W; };
+
+  // wave-uniform state: pops done, heap size, size of the original region still intact, postorder cursor (next position to
+  // turn into a pushed entry), preorder rank of the next candidate, the marker at the root (pixel, initial free mask, position)
+  int pops = 0, count = M, zn = M, ip = 1, qn = 0, cur_pos = 0;
+  int c = 0;
+  while (2 * c + 1 < M) c = 2 * c + 1;
+  uint32_t cur_e = M ? mlist[0] : 0u;
+  // (every window commits a pop or skips >= 64 dead candidates; the bound only guards the device against a defect in this
+  // code — an endless loop would take the GPU with it)
+  long long guard = 3LL * M + 64;
+  while (pops < M && --guard >= 0) {
+    // ---- candidates of this window: ONE round trip (+ one more for the few that still had a free neighbour at the start) ----
+    const int zn0 = zn, ip0 = ip;
+    const int T_pos = zn0 - 1 - lane >= 1 ? zn0 - 1 - lane : -1;
+    const int pr_i = ip0 + lane;
+    uint32_t T_e = 0, P_e = 0;
+    unsigned T_pk = 0, P_fl = 0x80000000u;
+    int P_pos = -1;
+    if (T_pos >= 0) { T_e = mlist[T_pos]; T_pk = PPC_LD(&TPK[T_pos]); }
+    if (pr_i < M) { P_e = PE[pr_i]; P_pos = (int)PPOS[pr_i]; P_fl = PPC_LD(&PFL[pr_i]); }
+    const int C_fm = (int)(PPC_LD(&TPK[cur_pos]) & 15u);                        // (uniform) the root marker's free neighbours
+    const int T_fm = (int)(T_pk & 15u);
+    const int P_fm = (int)(P_fl & 15u);
+    // ---- fast path: a run of markers that jump the queue -------------------------------------------------------------------------
+    // count == zn: the array's last entry is the original marker at zn - 1.  If the pop pushes nothing and that position has
+    // not converted, the marker jumps to the root and is the next pop — and so on down the array: pops cur, T0, T1, ... as long
+    // as each of them pushes nothing and the next position is still a marker.
+    if (count == zn && C_fm == 0) {
+      const bool okj = T_pos >= 0 && !ppc_post_before(T_pos, c);              // candidate `lane` can jump
+      const bool quiet = T_fm == 0;                                             // ... and its own pop pushes nothing
+      // R pops: cur, T0 .. T(R-2); pop i jumps candidate i.  Candidate i must be able to jump for i < R; pops 1 .. R-1 (= T0 ..
+      // T(R-2)) must be quiet.  R is limited by the markers left as well.
+      const unsigned long long nj = ~__ballot(okj), nq = ~__ballot(quiet);
+      int R = nj ? __ffsll((long long)nj) - 1 : 64;                              // candidates 0 .. R-1 can jump
+      const int Q = nq ? __ffsll((long long)nq) - 1 : 64;                        // candidates 0 .. Q-1 are quiet
+      if (R > Q + 1) R = Q + 1;
+      if (R > M - 1 - pops) R = M - 1 - pops;                                    // the last marker's pop is done below
+      if (R >= 1) {
+        if (lane < R) atomicOr(&PFL[T_pk >> 4], 0x80000000u);                   // they leave the preorder
+        pops += R; count -= R; zn -= R;
+        cur_pos = zn0 - R;                                                        // = position of candidate R-1
+        cur_e = (uint32_t)RL(T_e, R - 1);
+        if (c >= zn) c = (c - 1) >> 1;                                           // (the cursor's own position left the tree)
+        continue;
+      }
+    }
+    // ---- the general case: the automaton over up to 64 pops (wave-uniform values, scalar code) ---------------------------------
+    const int jt = P_pos >= 0 ? zn0 - 1 - P_pos : -1;                          // this preorder candidate's index in the tail list
+    unsigned long long pvalid = __ballot(P_pos >= 0 && !(P_fl >> 31));         // preorder candidates that have not jumped
+    // per-pop records, lane i = pop i: source (0 cur, 1 preorder, 2 tail) and index in its list, the tail candidate that
+    // jumped at the pop (or -1); state BEFORE the pop
+    int r_src = 0, r_idx = 0, r_jump = -1, s_pops = 0, s_count = 0, s_zn = 0, s_c = 0, s_ip = 0, s_cur = 0;
+    int src = 0, idx = 0, L = 0;
+    bool stop = false;
+    int e_pops = pops, e_count = count, e_zn = zn, e_c = c, e_ip = ip, e_cur = cur_pos;
+    for (int i = 0; i < PPS_W && !stop; ++i) {
+      r_src = pps_writelane(src, i, r_src); r_idx = pps_writelane(idx, i, r_idx);
+      s_pops = pps_writelane(e_pops, i, s_pops); s_count = pps_writelane(e_count, i, s_count);
+      s_zn = pps_writelane(e_zn, i, s_zn); s_c = pps_writelane(e_c, i, s_c);
+      s_ip = pps_writelane(e_ip, i, s_ip); s_cur = pps_writelane(e_cur, i, s_cur);
+      const int fm = src == 0 ? C_fm : src == 1 ? RL(P_fm, idx) : RL(T_fm, idx);
+      const int k = __builtin_popcount((unsigned)fm);
+      int n_pops = e_pops + 1, n_count = e_count - 1, n_zn = e_zn, n_c = e_c, n_ip = e_ip, n_cur = e_cur;
+      int n_src = 0, n_idx = 0, jumped_j = -1;
+      if (n_pops < M) {
+        const int tail = n_count;
+        bool sink = true;
+        if (tail < n_zn) {                             // the array is back inside the original region: tail == zn - 1
+          const int j = zn0 - 1 - tail;                // its index in the tail list
+          if (j >= PPS_W) { stop = true; break; }      // beyond the candidates of this window: the pop starts the next one
+          n_zn = tail;
+          if (!ppc_post_before(tail, n_c)) {           // still a marker: it jumps to the root
+            sink = false;
+            jumped_j = j;
+            pvalid &= ~__ballot(jt == j);              // ... and leaves the preorder
+            n_src = 2; n_idx = j; n_cur = tail;
+            if (n_c >= n_zn) n_c = (n_c - 1) >> 1;
+          }
+        }
+        if (sink) {
+          n_c = ppc_post_next(n_c, n_zn);              // one position converts
+          const unsigned long long rest = pvalid;
+          if (!rest) {                                 // every candidate left has jumped: they stay skipped, redo the pop
+            e_ip = ip0 + PPS_W < M ? ip0 + PPS_W : M;
+            stop = true; break;
+          }
+          const int q = __ffsll((long long)rest) - 1;  // the preorder-next marker that has not jumped
+          pvalid &= ~(1ull << q);
+          n_src = 1; n_idx = q; n_cur = RL(P_pos, q);
+          n_ip = ip0 + q + 1;
+        }
+      }
+      n_count += k;
+      r_jump = pps_writelane(jumped_j, i, r_jump);
+      e_pops = n_pops; e_count = n_count; e_zn = n_zn; e_c = n_c; e_ip = n_ip; e_cur = n_cur;
+      src = n_src; idx = n_idx;
+      L = i + 1;
+      if (n_pops >= M) stop = true;
+    }
+    // ---- lanes: pop `lane` claims its free neighbours; the window is cut at the first pop that lost one ---------------------
+    const bool mine = lane < L;
+    const int my_idx = r_idx & 63;
+    const uint32_t pe = __shfl(P_e, my_idx), te = __shfl(T_e, my_idx);
+    const int pfm = __shfl(P_fm, my_idx), tfm = __shfl(T_fm, my_idx);
+    const uint32_t e = r_src == 0 ? cur_e : r_src == 1 ? pe : te;
+    const int fm = mine ? (r_src == 0 ? C_fm : r_src == 1 ? pfm : tfm) : 0;
+    int T = L;
+    int total = 0;
+    if (__ballot(fm != 0)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (fm & (1 << s)) atomicMin(&claim[nbr(e, s)], (unsigned)(lane * 4 + s));
+      __threadfence();
+      bool lost = false;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (fm & (1 << s)) lost |= PPC_LD(&claim[nbr(e, s)]) != (unsigned)(lane * 4 + s);
+      const unsigned long long lmask = __ballot(lost);
+      if (lmask) T = __ffsll((long long)lmask) - 1;                    // >= 1: pop 0 has nobody before it
+      // ---- commit pops 0 .. T-1 ---------------------------------------------------------------------------------------------------
+      const int k = (lane < T) ? __builtin_popcount((unsigned)fm) : 0;
+      int off = k;                                      // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(off, o);
+        if (lane >= o) off += t;
+      }
+      total = __shfl(off, 63);
+      if (lane < T && fm) {
+        const int lab = out[e];                        // a marker's own label never changes
+        int w = qn + off - k;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (fm & (1 << s)) {
+            const uint32_t q = nbr(e, s);
+            queue[w++] = q; out[q] = lab;
+            // q is no longer free for any marker next to it (this one included): clear its bit in their masks
+            const int qy = (int)(q / (unsigned)W), qx = (int)(q - (unsigned)qy * W);
+            const bool nv[4] = {qy > 0, qx > 0, qx + 1 < W, qy + 1 < H};
+            const uint32_t nm[4] = {q - W, q - 1, q + 1, q + W};
+            const unsigned bit[4] = {8u, 4u, 2u, 1u};          // q is the DOWN / RIGHT / LEFT / UP neighbour of nm[.]
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              if (nv[d] && isMarker[nm[d]]) {
+                const unsigned old = atomicAnd(&TPK[MPOS[nm[d]]], ~bit[d]);
+                atomicAnd(&PFL[old >> 4], ~bit[d]);
+              }
+          }
+      }
+      if (lane >= T && fm) {                           // the pops that are redone take their claims back
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (fm & (1 << s)) {
+            const uint32_t q = nbr(e, s);
+            if ((PPC_LD(&claim[q]) >> 2) >= (unsigned)T) claim[q] = 0xffffffffu;
+          }
+      }
+    }
+    // markers that jumped at a committed pop stay out of the preorder for good
+    const int jrank = __shfl((int)(T_pk >> 4), (r_jump >= 0 ? r_jump : 0) & 63);     // preorder rank of that tail candidate
+    if (lane < T && r_jump >= 0) atomicOr(&PFL[jrank], 0x80000000u);
+    __threadfence();
+    // ---- state after pop T-1 = state before pop T ------------------------------------------------------------------------------
+    qn += total;
+    if (T < L) {
+      pops = RL(s_pops, T); count = RL(s_count, T); zn = RL(s_zn, T); c = RL(s_c, T); ip = RL(s_ip, T);
+      cur_pos = RL(s_cur, T);
+      cur_e = (uint32_t)RL(e, T);
+    } else {
+      pops = e_pops; count = e_count; zn = e_zn; c = e_c; ip = e_ip; cur_pos = e_cur;
+      if (L > 0 && pops < M) {                         // the marker the last pop put at the root
+        cur_e = src == 1 ? (uint32_t)RL(P_e, idx) : (uint32_t)RL(T_e, idx);
+      }
+    }
+  }
+  if (lane == 0) {
+    counters[C_CONST_Q] = qn;
+    counters[C_SCRATCH] = 1;                             // status bit 0: the exact single-wavefront marker phase was used
+    if (pops < M) counters[C_TAINT] = 0x40;              // (never seen: the guard fired)
+  }
+#undef RL
 #undef PPC_LD
 }
 
@@ -1243,8 +1539,19 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
                      g_ppw_rows);
   if (force_serial) {
     // constant image (boundary method): serial heap phase for the age-0 markers, then an ordered parallel BFS
-    hipLaunchKernelGGL(pp_flood_const_init_kernel, dim3(1), dim3(PPC_THREADS), 0, st, (const int32_t*)w.markers,
-                       (uint32_t*)w.clist, (uint32_t*)w.hoff, w.out, H, W, w.counters);
+    hipLaunchKernelGGL(pp_flood_const_flag_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.markers, n, w.flag,
+                       (uint32_t*)w.hoff, w.out);
+    if (pp_exclusive_scan(w.flag, w.scan, w.bsum, n, w.counters + C_CONST_M, st)) return MSEG_ELAUNCH;
+    hipLaunchKernelGGL(pp_flood_const_list_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.flag,
+                       (const int32_t*)w.scan, n, (uint32_t*)w.clist, w.counters, g_ppc_stream);
+    // marker phase: the closed form of the heap's behaviour when every key ties (the flag is cleared if they do not) ...
+    hipLaunchKernelGGL(pp_flood_const_orders_kernel, dim3(256 * 4), dim3(256), 0, st, img, (const uint8_t*)w.mask,
+                       (const int32_t*)w.out, (const uint32_t*)w.clist, H, W, (uint32_t*)w.bymin, (uint32_t*)w.bymax,
+                       (uint32_t*)w.bxmin, (uint32_t*)w.bxmax, (uint32_t*)w.carea, w.counters);
+    hipLaunchKernelGGL(pp_flood_const_stream_kernel, dim3(1), dim3(64), 0, st, (const uint8_t*)w.mask, (uint32_t*)w.clist,
+                       (uint32_t*)w.hoff, (const uint32_t*)w.bymin, (const uint32_t*)w.bymax, (uint32_t*)w.bxmin,
+                       (uint32_t*)w.bxmax, (const uint32_t*)w.carea, (const int32_t*)w.flag, w.out, H, W, w.counters);
+    // ... or, for keys that differ, the replay of the heap itself
     hipLaunchKernelGGL(pp_flood_const_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask, w.hkey,
                        w.hidx, (uint32_t*)w.clist, w.out, H, W, w.counters);
     hipLaunchKernelGGL(pp_flood_const_bfs_kernel, dim3(1), dim3(PPC_THREADS), 0, st, (const uint8_t*)w.mask,
@@ -1282,6 +1589,11 @@ static int pp_distance_tail(const PPWs& w, const float* border, int H, int W, fl
 
 // Test / tuning hook: rows of the per-wave queue kept in LDS (1..16) and the two tile capacities in pixels (small <= 8192,
 // large <= 30720; 0 = probe global memory for every component).  Process-wide; negative values restore the defaults.
+extern "C" int mseg_postproc_set_const_stream(int on) {
+  g_ppc_stream = on ? 1 : 0;
+  return MSEG_OK;
+}
+
 extern "C" int mseg_postproc_tuning(int heap_rows, int tile_small_px, int tile_large_px) {
   if (heap_rows == 0 || heap_rows > PPW_ROWS || tile_small_px > PPW_TILE_S || tile_large_px > PPW_TILE_L ||
       (tile_small_px >= 0 && tile_large_px >= 0 && tile_large_px < tile_small_px))

@@ -32,8 +32,19 @@ def test_distance_postprocessing_matches_reference(name, pp):
         assert np.array_equal(got2, fx[f"labels_2d_{j}"]), f"{name}[{j}] (2-D input, raster ids)"
 
 
+@pytest.fixture(params=[1, 0], ids=["marker_phase_closed_form", "marker_phase_heap_replay"])
+def const_stream(request):
+    """the marker phase of the constant-image flood both ways (mseg_postproc_set_const_stream): the closed form of the heap's
+    behaviour with equal keys (default) and the replay of the heap itself"""
+    from microbeseg_amd import _lib
+    lib = _lib.load()
+    assert lib.mseg_postproc_set_const_stream(request.param) == 0
+    yield request.param
+    lib.mseg_postproc_set_const_stream(1)
+
+
 @pytest.mark.parametrize("name", ["boundary_generic", "boundary_touching"])
-def test_boundary_postprocessing_matches_reference(name, pp):
+def test_boundary_postprocessing_matches_reference(name, pp, const_stream):
     fx = load_npz(f"postproc_{name}.npz")
     got = pp.boundary_postprocessing(fx["probs"])
     assert np.array_equal(got, fx["labels"]), f"{(got != fx['labels']).sum()} px differ"
@@ -129,10 +140,12 @@ def test_tie_stress_fast_path_stays_exact(levels, pp):
         assert tied_parallel > 0, "no frame with tied seed values went through the parallel path"
 
 
-@pytest.mark.parametrize("H,W,n,seed", [(200, 260, 60, 1), (384, 512, 260, 2), (97, 131, 25, 3)])
-def test_boundary_postprocessing_matches_oracle_random(H, W, n, seed, pp):
+@pytest.mark.parametrize("H,W,n,seed", [(200, 260, 60, 1), (384, 512, 260, 2), (97, 131, 25, 3), (700, 900, 900, 4),
+                                        (64, 2048, 120, 5), (33, 17, 3, 6)])
+def test_boundary_postprocessing_matches_oracle_random(H, W, n, seed, pp, const_stream):
     """Boundary method on random frames with leaky boundaries (several seeds per mask component, so labels meet inside
-    components and every tie is decided by the age order): serial marker phase + ordered parallel BFS vs the C oracle."""
+    components and every tie is decided by the age order): marker phase (closed form / heap replay) + ordered parallel BFS
+    vs the C oracle."""
     from microbeseg_amd.utils import synth
     from oracle import postproc_ref
     rng = np.random.Generator(np.random.PCG64(900 + seed))

@@ -1,18 +1,36 @@
-import sys, time, pathlib
-sys.path.insert(0, "/root/repo")
-import numpy as np, torch
-from microbeseg_amd.utils import synth
+"""GPU box: the boundary method's post-processing (reference postprocessing.py:62-90) on a synthetic 2048^2 frame with
+~2500 cells — the closed-form marker phase (mseg_postproc_set_const_stream(1), default) against the replay of the heap (0):
+time per frame, equal labels, and both against the C oracle."""
+import sys, pathlib, time
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch
+import bench
+from microbeseg_amd import _lib
 from microbeseg_amd.inference import postprocessing as pp
-for S in (512, 1024, 2048):
-    rng = np.random.Generator(np.random.PCG64(7))
-    cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2), rmin=5.0, rmax=13.0)
-    # boundary-method style probabilities: interior where cell high & border low, boundary where border high, else bg
-    p1 = np.clip(cell * 2.0, 0, 1) * (1 - np.clip(border * 1.2, 0, 1))
-    p2 = np.clip(border * 1.2, 0, 1) * (cell > 0.02)
-    p0 = np.clip(1 - p1 - p2, 0.0, 1)
-    probs = np.stack([p0, p1, p2], -1).astype(np.float32)
-    probs /= probs.sum(-1, keepdims=True)
-    t = torch.from_numpy(probs).cuda()
-    lab, n, st = pp.boundary_postprocessing_device(t); torch.cuda.synchronize()
-    t0 = time.time(); lab, n, st = pp.boundary_postprocessing_device(t); torch.cuda.synchronize(); dt = time.time() - t0
-    print(S, "boundary postproc %.1f ms" % (dt * 1e3), "instances", int(n), "status", int(st), "fg", float((lab != 0).float().mean()))
+from microbeseg_amd.utils import synth
+from oracle import postproc_ref
+
+lib = _lib.load()
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+rng = np.random.default_rng(5)
+cell, border = synth.synth_prediction_maps(rng, S, S, int(2500 * (S / 2048.0) ** 2), rmin=5.0, rmax=13.0)
+probs = torch.from_numpy(bench._boundary_probs(cell, border)).cuda()
+res = {}
+for mode in (1, 0):
+    lib.mseg_postproc_set_const_stream(mode)
+    pp.boundary_postprocessing_device(probs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        bl, bn, bs = pp.boundary_postprocessing_device(probs)
+    e1.record()
+    torch.cuda.synchronize()
+    res[mode] = bl.cpu().numpy().view(np.uint16)
+    print(f"const_stream={mode}: {e0.elapsed_time(e1) / 3:8.2f} ms per frame, {int(bn)} instances, status {int(bs)}", flush=True)
+lib.mseg_postproc_set_const_stream(1)
+print("stream == heap replay:", bool(np.array_equal(res[0], res[1])))
+t0 = time.perf_counter()
+want = postproc_ref.boundary_postprocessing(probs.cpu().numpy())
+print(f"C oracle {time.perf_counter() - t0:.2f} s; == oracle:", bool(np.array_equal(res[1], want)))
