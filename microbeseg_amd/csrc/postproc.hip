@@ -1136,10 +1136,13 @@ __global__ void pp_flood_const_orders_kernel(const float* __restrict__ img, cons
                                              const int32_t* __restrict__ out, const uint32_t* __restrict__ queue, int H, int W,
                                              uint32_t* __restrict__ PE, uint32_t* __restrict__ PPOS,
                                              uint32_t* __restrict__ PFL, uint32_t* __restrict__ TPK,
-                                             uint32_t* __restrict__ MPOS, int32_t* __restrict__ counters) {
+                                             uint32_t* __restrict__ MPOS, uint32_t* __restrict__ JB,
+                                             int32_t* __restrict__ counters) {
   if (!counters[C_SERIAL]) return;
   const size_t n = (size_t)H * W;
   const unsigned M = (unsigned)counters[C_CONST_M];
+  // JB: one bit per preorder rank, set when that marker has jumped the queue (the preorder stream skips it)
+  for (unsigned wd = blockIdx.x * blockDim.x + threadIdx.x; wd < (M + 31u) / 32u; wd += gridDim.x * blockDim.x) JB[wd] = 0u;
   const uint32_t* mlist = queue + (n - (size_t)M);
   const float v0 = M ? img[mlist[0]] : 0.f;
   bool equal = true;
@@ -1196,7 +1199,7 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
     const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
     const uint32_t* __restrict__ PE, const uint32_t* __restrict__ PPOS, uint32_t* __restrict__ PFL,
     uint32_t* __restrict__ TPK, const uint32_t* __restrict__ MPOS, const int32_t* __restrict__ isMarker,
-    int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+    uint32_t* __restrict__ JB, int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
   if (!counters[C_SERIAL] || !counters[C_CONST_STREAM]) return;
   const size_t n = (size_t)H * W;
   const int lane = threadIdx.x;
@@ -1219,15 +1222,16 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
     // ---- candidates of this window: ONE round trip (+ one more for the few that still had a free neighbour at the start) ----
     const int zn0 = zn, ip0 = ip;
     const int T_pos = zn0 - 1 - lane >= 1 ? zn0 - 1 - lane : -1;
-    const int pr_i = ip0 + lane;
     uint32_t T_e = 0, P_e = 0;
-    unsigned T_pk = 0, P_fl = 0x80000000u;
-    int P_pos = -1;
+    unsigned T_pk = 0, P_fl = 0u;
+    int P_pos = -1, P_rank = M;
     if (T_pos >= 0) { T_e = mlist[T_pos]; T_pk = PPC_LD(&TPK[T_pos]); }
-    if (pr_i < M) { P_e = PE[pr_i]; P_pos = (int)PPOS[pr_i]; P_fl = PPC_LD(&PFL[pr_i]); }
+    // the jumped-bitmap words of the next 2048 preorder ranks (used below if the window is not a plain run of jumps)
+    const int w0 = ip0 >> 5;
+    unsigned jbw = 0xffffffffu;
+    if ((long long)(w0 + lane) * 32 < M) jbw = PPC_LD(&JB[w0 + lane]);
     const int C_fm = (int)(PPC_LD(&TPK[cur_pos]) & 15u);                        // (uniform) the root marker's free neighbours
     const int T_fm = (int)(T_pk & 15u);
-    const int P_fm = (int)(P_fl & 15u);
     // ---- fast path: a run of markers that jump the queue -------------------------------------------------------------------------
     // count == zn: the array's last entry is the original marker at zn - 1.  If the pop pushes nothing and that position has
     // not converted, the marker jumps to the root and is the next pop — and so on down the array: pops cur, T0, T1, ... as long
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
       if (R > Q + 1) R = Q + 1;
       if (R > M - 1 - pops) R = M - 1 - pops;                                    // the last marker's pop is done below
       if (R >= 1) {
-        if (lane < R) atomicOr(&PFL[T_pk >> 4], 0x80000000u);                   // they leave the preorder
+        if (lane < R) atomicOr(&JB[T_pk >> 9], 1u << ((T_pk >> 4) & 31u));       // they leave the preorder
         pops += R; count -= R; zn -= R;
         cur_pos = zn0 - R;                                                        // = position of candidate R-1
         cur_e = (uint32_t)RL(T_e, R - 1);
@@ -1251,16 +1255,82 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
         continue;
       }
     }
-    // ---- the general case: the automaton over up to 64 pops (wave-uniform values, scalar code) ---------------------------------
+    // ---- the general case ------------------------------------------------------------------------------------------------------
+    // preorder candidates: the next 64 ranks >= ip whose marker has NOT jumped, packed (late in a frame most of the deeper
+    // markers have jumped: 64 consecutive ranks would hold only a few live ones and starve the window)
+    {
+      unsigned valid = ~jbw;
+      if (lane == 0) valid &= 0xffffffffu << (ip0 & 31);                         // ranks below ip are done
+      const long long base = (long long)(w0 + lane) * 32;
+      if (base + 32 > M) valid &= (base >= M) ? 0u : (0xffffffffu >> (32 - (int)(M - base)));
+      const int cnt = __builtin_popcount(valid);
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const int excl = incl - cnt;
+      const int ptotal = __shfl(incl, 63);
+      if (ptotal == 0 && ip0 < M) {                                              // 2048 ranks without a live marker: move on
+        const long long nip = (long long)(w0 + 64) * 32;
+        ip = nip < M ? (int)nip : M;
+        continue;
+      }
+      // lane l takes the l-th live rank: the word whose exclusive count is the last one <= l, then the bit inside it
+      int wl = 0;
+#pragma unroll
+      for (int stp = 32; stp >= 1; stp >>= 1) {
+        const int cand = wl + stp;
+        const int v = __shfl(excl, cand & 63);
+        if (cand < 64 && v <= lane) wl = cand;
+      }
+      unsigned wv = (unsigned)__shfl((int)valid, wl);
+      int kth = lane - __shfl(excl, wl);
+      if (lane < ptotal) {
+        while (kth-- > 0) wv &= wv - 1u;
+        P_rank = (w0 + wl) * 32 + (__ffs((int)wv) - 1);
+        P_e = PE[P_rank]; P_pos = (int)PPOS[P_rank]; P_fl = PPC_LD(&PFL[P_rank]);
+      }
+    }
+    const int P_fm = (int)(P_fl & 15u);
     const int jt = P_pos >= 0 ? zn0 - 1 - P_pos : -1;                          // this preorder candidate's index in the tail list
-    unsigned long long pvalid = __ballot(P_pos >= 0 && !(P_fl >> 31));         // preorder candidates that have not jumped
+    unsigned long long pvalid = __ballot(P_pos >= 0);                          // live preorder candidates, in rank order
     // per-pop records, lane i = pop i: source (0 cur, 1 preorder, 2 tail) and index in its list, the tail candidate that
     // jumped at the pop (or -1); state BEFORE the pop
     int r_src = 0, r_idx = 0, r_jump = -1, s_pops = 0, s_count = 0, s_zn = 0, s_c = 0, s_ip = 0, s_cur = 0;
     int src = 0, idx = 0, L = 0;
     bool stop = false;
     int e_pops = pops, e_count = count, e_zn = zn, e_c = c, e_ip = ip, e_cur = cur_pos;
+    const unsigned long long quietmask = __ballot(T_fm == 0);
+    int jev = -1;                                      // lane = tail candidate: the recorded pop in front of which it jumped in a run
     for (int i = 0; i < PPS_W && !stop; ++i) {
+      // a run of markers jumping the queue (as in the fast path above), retired in one step inside the window: the root
+      // marker pushes nothing and the array is exactly the intact prefix.  Only pops that push, sink or convert go through
+      // the scalar code below (~200 instructions each for a lone wavefront).
+      {
+        const int fm0 = src == 0 ? C_fm : src == 1 ? RL(P_fm, idx) : RL(T_fm, idx);
+        const int j0 = zn0 - e_zn;                     // index of the array's last slot in the tail list
+        if (fm0 == 0 && e_count == e_zn && j0 < PPS_W && e_pops < M - 1) {
+          const unsigned long long okm = __ballot(T_pos >= 0 && !ppc_post_before(T_pos, e_c)) >> j0;
+          const unsigned long long qm = quietmask >> j0;
+          int R = __ffsll((long long)~okm) - 1;        // (the shift brought zeros in at the top: ~okm is never 0 for j0 > 0)
+          if (~okm == 0ull) R = 64;
+          int Q = __ffsll((long long)~qm) - 1;
+          if (~qm == 0ull) Q = 64;
+          if (R > Q + 1) R = Q + 1;
+          if (R > PPS_W - j0) R = PPS_W - j0;
+          if (R > M - 1 - e_pops) R = M - 1 - e_pops;
+          if (R >= 1) {
+            if (lane >= j0 && lane < j0 + R) jev = i;
+            pvalid &= ~__ballot(jt >= j0 && jt < j0 + R);
+            e_pops += R; e_count -= R; e_zn -= R;
+            e_cur = zn0 - j0 - R;                      // position of the last one: it sits at the root now
+            src = 2; idx = j0 + R - 1;
+            if (e_c >= e_zn) e_c = (e_c - 1) >> 1;
+          }
+        }
+      }
       r_src = pps_writelane(src, i, r_src); r_idx = pps_writelane(idx, i, r_idx);
       s_pops = pps_writelane(e_pops, i, s_pops); s_count = pps_writelane(e_count, i, s_count);
       s_zn = pps_writelane(e_zn, i, s_zn); s_c = pps_writelane(e_c, i, s_c);
@@ -1287,14 +1357,11 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
         if (sink) {
           n_c = ppc_post_next(n_c, n_zn);              // one position converts
           const unsigned long long rest = pvalid;
-          if (!rest) {                                 // every candidate left has jumped: they stay skipped, redo the pop
-            e_ip = ip0 + PPS_W < M ? ip0 + PPS_W : M;
-            stop = true; break;
-          }
+          if (!rest) { stop = true; break; }           // the preorder candidates of this window are used up: redo the pop
           const int q = __ffsll((long long)rest) - 1;  // the preorder-next marker that has not jumped
           pvalid &= ~(1ull << q);
           n_src = 1; n_idx = q; n_cur = RL(P_pos, q);
-          n_ip = ip0 + q + 1;
+          n_ip = RL(P_rank, q) + 1;
         }
       }
       n_count += k;
@@ -1365,7 +1432,8 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
     }
     // markers that jumped at a committed pop stay out of the preorder for good
     const int jrank = __shfl((int)(T_pk >> 4), (r_jump >= 0 ? r_jump : 0) & 63);     // preorder rank of that tail candidate
-    if (lane < T && r_jump >= 0) atomicOr(&PFL[jrank], 0x80000000u);
+    if (lane < T && r_jump >= 0) atomicOr(&JB[jrank >> 5], 1u << (jrank & 31));
+    if (jev >= 0 && jev <= T) atomicOr(&JB[T_pk >> 9], 1u << ((T_pk >> 4) & 31u));    // runs in front of a committed pop
     __threadfence();
     // ---- state after pop T-1 = state before pop T ------------------------------------------------------------------------------
     qn += total;
@@ -1375,7 +1443,7 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
       cur_e = (uint32_t)RL(e, T);
     } else {
       pops = e_pops; count = e_count; zn = e_zn; c = e_c; ip = e_ip; cur_pos = e_cur;
-      if (L > 0 && pops < M) {                         // the marker the last pop put at the root
+      if (pops < M && src != 0) {                      // the marker the last pop (or run) put at the root
         cur_e = src == 1 ? (uint32_t)RL(P_e, idx) : (uint32_t)RL(T_e, idx);
       }
     }
@@ -1547,10 +1615,11 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
     // marker phase: the closed form of the heap's behaviour when every key ties (the flag is cleared if they do not) ...
     hipLaunchKernelGGL(pp_flood_const_orders_kernel, dim3(256 * 4), dim3(256), 0, st, img, (const uint8_t*)w.mask,
                        (const int32_t*)w.out, (const uint32_t*)w.clist, H, W, (uint32_t*)w.bymin, (uint32_t*)w.bymax,
-                       (uint32_t*)w.bxmin, (uint32_t*)w.bxmax, (uint32_t*)w.carea, w.counters);
+                       (uint32_t*)w.bxmin, (uint32_t*)w.bxmax, (uint32_t*)w.carea, (uint32_t*)w.hidx, w.counters);
     hipLaunchKernelGGL(pp_flood_const_stream_kernel, dim3(1), dim3(64), 0, st, (const uint8_t*)w.mask, (uint32_t*)w.clist,
                        (uint32_t*)w.hoff, (const uint32_t*)w.bymin, (const uint32_t*)w.bymax, (uint32_t*)w.bxmin,
-                       (uint32_t*)w.bxmax, (const uint32_t*)w.carea, (const int32_t*)w.flag, w.out, H, W, w.counters);
+                       (uint32_t*)w.bxmax, (const uint32_t*)w.carea, (const int32_t*)w.flag, (uint32_t*)w.hidx, w.out, H, W,
+                       w.counters);
     // ... or, for keys that differ, the replay of the heap itself
     hipLaunchKernelGGL(pp_flood_const_serial_kernel, dim3(1), dim3(64), 0, st, img, (const uint8_t*)w.mask, w.hkey,
                        w.hidx, (uint32_t*)w.clist, w.out, H, W, w.counters);
