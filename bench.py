@@ -602,6 +602,17 @@ def train_metric(args, dev, world, rank, timing=True):
     return out, net
 
 
+def release(*objs):
+    """Drop a finished block's network for good before the next block is timed: the packed-weight caches and the optimizer's
+    arenas sit in reference cycles (param -> pack -> param), so `del` alone leaves gigabytes to the cyclic collector — which
+    then runs, and returns them to the allocator, somewhere inside a later block's timed loop."""
+    import gc
+    del objs
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def main():
     args = parse()
     in_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -638,8 +649,8 @@ def main():
     headline = workload_key(args) == {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn",
                                       "filters": [64, 1024], "optimizer": "adam", "precision": "fp32"}
     del net
+    release()
     if rank == 0 and world == 1 and not args.no_inference and args.arch == "DU":
-        torch.cuda.empty_cache()
         # a freshly initialised network (fixed seed): the few optimisation steps above on random labels leave a network whose
         # outputs are nearly constant, i.e. frames without seeds and a watershed with nothing to do
         from microbeseg_amd.utils.unets import build_unet
@@ -647,7 +658,7 @@ def main():
         net_i = build_unet(args.arch, args.act, "conv", args.norm, dev, 1, ch_out=1, filters=tuple(args.filters))
         out["inference"] = inference_metric(args, net_i, dev)
         del net_i
-    torch.cuda.empty_cache()
+    release()
     if rank == 0 and world == 1 and headline and not args.no_bf16_block:
         # BASELINE configs[2] next to the fp32 headline, so that the driver's default run records it too
         import copy
@@ -656,7 +667,7 @@ def main():
         a2.steps, a2.warmup = max(args.steps, 10), max(args.warmup, 3)
         blk, net2 = train_metric(a2, dev, 1, 0, timing=not args.no_kernel_timing)   # two-pass timing, see train_metric
         del net2
-        torch.cuda.empty_cache()
+        release()
         engine.set_precision(args.precision)
         out["bf16_320"] = blk
         # further configurations of the path, each a short run with its own roofline: the boundary method's
@@ -673,7 +684,7 @@ def main():
                 setattr(a3, k_, v_)
             blk, net3 = train_metric(a3, dev, 1, 0, timing=not args.no_kernel_timing)
             del net3
-            torch.cuda.empty_cache()
+            release()
             blk.pop("kernels", None)                     # the per-instantiation table stays with the two main blocks
             if a3.batch == 4:
                 # batch 4 (the GUI / CLI default), ~600 launches per step: the same step replayed from a hipGraph
@@ -682,7 +693,7 @@ def main():
                 a4.graph = True
                 rep, net4 = train_metric(a4, dev, 1, 0, timing=False)
                 del net4
-                torch.cuda.empty_cache()
+                release()
                 blk["graph_replay"] = {k: rep[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step")}
             out["secondary"][tag] = blk
         engine.set_precision(args.precision)

@@ -7,9 +7,10 @@ from microbeseg_amd.utils.unets import build_unet
 from microbeseg_amd.training.losses import get_loss
 from microbeseg_amd.training.optim import make_adam
 prec, size, batch = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+norm = sys.argv[4] if len(sys.argv) > 4 else "bn"
 engine.set_precision(prec)
 dev = torch.device("cuda:0")
-net = build_unet("DU", "relu", "conv", "bn", dev, 1, filters=(64, 1024))
+net = build_unet("DU", "relu", "conv", norm, dev, 1, filters=(64, 1024))
 opt = make_adam(net.parameters())
 crit = get_loss("smooth_l1", "distance")
 x = torch.rand(batch, 1, size, size, device=dev) * 2 - 1
@@ -34,4 +35,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
