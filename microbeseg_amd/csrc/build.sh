@@ -11,10 +11,15 @@ pids=()
 for s in $SRCS; do
   o=../_build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ igemm_common.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ igemm_common.h -nt "$o" ] || [ bf16_affine.h -nt "$o" ] || [ ../../include/mseg_hip.h -nt "$o" ]; then
     # -pragma-unroll-threshold: the fully unrolled epilogues exceed LLVM's default 16k-instruction cap for "#pragma unroll";
     # a loop left rolled would index the accumulator array dynamically and push it to scratch memory
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=200000 -c "$s" -o "$o" &
+    # -fno-slp-vectorize for the matrix kernels: the SLP vectorizer turns the staging code's scalar fp32 multiply-adds into
+    # v_pk_fma_f32 / v_pk_mul_f32, which beside MFMAs cost more than the two scalar instructions they replace
+    # (MI355X_MICROARCH.md, cycle constants; measured here: bf16 320^2 step 38.13 -> 37.68 ms, fp32 neutral)
+    extra=""
+    case "$s" in igemm.hip|igemm_p8.hip|wgrad.hip) extra="-fno-slp-vectorize";; esac
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=200000 $extra -c "$s" -o "$o" &
     pids+=($!)
   fi
 done

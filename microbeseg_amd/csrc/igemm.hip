@@ -23,6 +23,7 @@
 // issued before the MFMAs of step s and consumed (activation, scale/shift, ds_write) after them.
 #include "common.h"
 #include "igemm_common.h"
+#include "bf16_affine.h"
 
 // igemm_p8.hip: one 8-wave workgroup per CU with DMA-streamed weights (>= 128 output channels, bf16 tensors)
 int igemm_p8_try(const MsegIgemm& p, int tr, int m_fastest, int cus, hipStream_t st);
@@ -910,6 +911,9 @@ __device__ __forceinline__ void igemm_halo_bf16_body(const MsegIgemm& p, int tw_
           const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
           if (TR == 0) {                             // plain bf16 operand: already in LDS format
             *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else if (TR == 1) {                       // ReLU / none + affine: the short form (bf16_affine.h)
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) =
+                mseg_affine8_bf16(raw, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, rsc, rsh, rsc2, rsh2, m != 0.f);
           } else {
             const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
             const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
@@ -1165,6 +1169,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4_kernel(const MsegIge
           const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
           if (TR == 0) {                             // plain bf16 operand: already in LDS format
             *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else if (TR == 1) {                       // ReLU / none + affine: the short form (bf16_affine.h)
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) =
+                mseg_affine8_bf16(raw, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, rsc, rsh, rsc2, rsh2, m != 0.f);
           } else {
             const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
             const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
@@ -1437,6 +1444,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_bf16w4m_kernel(const MsegIg
           const uint4 raw = __builtin_bit_cast(uint4, rh[j]);
           if (TR == 0) {                             // plain bf16 operand: already in LDS format
             *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) = raw;
+          } else if (TR == 1) {                       // ReLU / none + affine: the short form (bf16_affine.h)
+            *reinterpret_cast<uint4*>(As + hrow * HB_STRIDE + scol * 8) =
+                mseg_affine8_bf16(raw, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, rsc, rsh, rsc2, rsh2, m != 0.f);
           } else {
             const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
             const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);
@@ -1705,10 +1715,14 @@ __global__ __launch_bounds__(512, 1) void igemm_c64p_bf16_kernel(const MsegIgemm
       if (!((hgeo >> j) & 1u)) continue;
       uint4 v = rh[j];
       if (TR != 0) {                                    // (TR == 0: a plain bf16 operand is already in LDS format)
-        const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
-        const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
-        const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
-        v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+        if (TR == 1) {                                  // ReLU / none + affine: the short form (bf16_affine.h)
+          v = mseg_affine8_bf16(v, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, tsc[0], tsh[0], tsc[1], tsh[1], true);
+        } else {
+          const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
+          const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
+          const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+          v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+        }
       }
       if (!((hlive >> j) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);     // zero padding / rows outside the image
       *reinterpret_cast<uint4*>(Hl + (srow + 32 * j) * C64_STRIDE + scol * 8) = v;
@@ -1921,10 +1935,14 @@ __global__ __launch_bounds__(512, 1) void igemm_ctp_bf16_kernel(const MsegIgemm 
     for (int j = 0; j < HL; ++j) {
       uint4 v = rh[j];
       if (TR != 0) {
-        const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
-        const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
-        const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
-        v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+        if (TR == 1) {                                  // ReLU / none + affine: the short form (bf16_affine.h)
+          v = mseg_affine8_bf16(v, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, tsc[0], tsh[0], tsc[1], tsh[1], true);
+        } else {
+          const float4 a = xform4(bf16x4_to_f32(make_uint2(v.x, v.y)), tsc[0], tsh[0], lo);
+          const float4 b = xform4(bf16x4_to_f32(make_uint2(v.z, v.w)), tsc[1], tsh[1], lo);
+          const uint2 pa = f32x4_to_bf16(a), pb = f32x4_to_bf16(b);
+          v = make_uint4(pa.x, pa.y, pb.x, pb.y);
+        }
       }
       *reinterpret_cast<uint4*>(Al + (srow + 16 * j) * CTP_STRIDE + scol * 8) = v;
     }
@@ -2088,6 +2106,7 @@ __global__ __launch_bounds__(512, 1) void igemm_ctp2_bf16_kernel(const MsegIgemm
   };
   auto xf8 = [&](uint4 v) -> uint4 {
     if (TR == 0) return v;
+    if (TR == 1) return mseg_affine8_bf16(v, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, tsc[0], tsh[0], tsc[1], tsh[1], true);
     const float lo = (ract == MSEG_ACT_RELU) ? 0.f : -3.402823466e38f;
     float4 a = bf16x4_to_f32(make_uint2(v.x, v.y)), b = bf16x4_to_f32(make_uint2(v.z, v.w));
     if (TR == 2) { a = act_fwd4(a, ract); b = act_fwd4(b, ract); }
@@ -2459,6 +2478,9 @@ __global__ __launch_bounds__(256, PER_SAMPLE ? 2 : 4) void igemm_fast_bf16_kerne
         const uint4 raw = __builtin_bit_cast(uint4, ra[i]);
         if (TR == 0) {
           *reinterpret_cast<uint4*>(As + (srow + RS * i) * HB_STRIDE + scol * 8) = raw;
+        } else if (TR == 1) {                          // ReLU / none + affine: the short form (bf16_affine.h)
+          *reinterpret_cast<uint4*>(As + (srow + RS * i) * HB_STRIDE + scol * 8) =
+              mseg_affine8_bf16(raw, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, rsc[ti], rsh[ti], rsc2[ti], rsh2[ti], rm[i] != 0.f);
         } else {
           const float4 u = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc[ti], rsh[ti], lo, rm[i]);
           const float4 w = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2[ti], rsh2[ti], lo, rm[i]);

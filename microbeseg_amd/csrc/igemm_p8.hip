@@ -18,6 +18,7 @@
 // Stage order inside a 32-channel chunk: the 9 taps; the halo of chunk c + 1 is fetched into registers at tap 0 of chunk
 // c, normalised (act + scale / shift: norm-on-load) and written to the OTHER halo buffer at tap 5.
 #include "igemm_common.h"
+#include "bf16_affine.h"
 #include <stdlib.h>
 
 typedef __bf16 p8_bf16x8 __attribute__((ext_vector_type(8)));
@@ -416,6 +417,11 @@ __global__ __launch_bounds__(512, 2) void igemm_p8_kernel(const MsegIgemm p, con
       const float4 rsc2 = make_float4(c1[0] + tone, c1[1] + tone, c1[2] + tone, c1[3] + tone);
       const float4 rsh = make_float4(h0[0], h0[1], h0[2], h0[3]);
       const float4 rsh2 = make_float4(h1[0], h1[1], h1[2], h1[3]);
+      if (TR == 1) {
+        *reinterpret_cast<uint4*>(dstp) = mseg_affine8_bf16(raw, ract == MSEG_ACT_RELU ? 0u : 0x80008000u, rsc, rsh, rsc2, rsh2,
+                                                            ((hlive >> j) & 1u) != 0u);
+        return;
+      }
       const float m = ((hlive >> j) & 1u) ? 1.f : 0.f;
       const float4 a = xform4(bf16x4_to_f32(make_uint2(raw.x, raw.y)), rsc, rsh, lo, m);
       const float4 b = xform4(bf16x4_to_f32(make_uint2(raw.z, raw.w)), rsc2, rsh2, lo, m);

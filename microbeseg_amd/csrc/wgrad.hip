@@ -11,6 +11,7 @@
 // load, so the normalised activation is never stored.  Stages are double buffered in LDS: one barrier per
 // KW x 16 MFMAs.  Partial sums go to a split-K workspace that is reduced in fixed order (deterministic).
 #include "common.h"
+#include "bf16_affine.h"
 
 #define WG_PIX 32
 #define WG_LDS 68
@@ -1045,6 +1046,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
       const uint4 r = __builtin_bit_cast(uint4, raw);
       if (tr == 0) {
         *reinterpret_cast<uint4*>(stage + e) = r;
+      } else if (tr == 1) {
+        *reinterpret_cast<uint4*>(stage + e) = mseg_affine8_bf16(r, lo == 0.f ? 0u : 0x80008000u, sc, sh, sc2, sh2, m != 0.f);
       } else {
         const uint2 a = f32x4_to_bf16(xf(bf16x4_to_f32(make_uint2(r.x, r.y)), sc, sh, act, lo, m, tr));
         const uint2 b = f32x4_to_bf16(xf(bf16x4_to_f32(make_uint2(r.z, r.w)), sc2, sh2, act, lo, m, tr));
