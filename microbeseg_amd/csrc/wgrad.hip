@@ -956,11 +956,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
   const unsigned pv0 = (unsigned)(pr0 * p.Wp + (spx & (TW - 1))) * mC4 + (unsigned)(mvalid ? mc : 0) * (unsigned)ESZ;
   const unsigned pvstep = (unsigned)((RP >> TWL) * p.Wp) * mC4;                  // scalar
   int qrj[NQ];                                         // halo row << 8 | halo column
-#pragma unroll
+  unsigned qoff[NQ];                                   // byte offset of that halo pixel (this thread's channels) from the
+#pragma unroll                                         // block's halo origin: the per-step part is ONE scalar
   for (int i = 0; i < NQ; ++i) {
     const int sidx = spx + RP * i;
     const int r = sidx / QW, c = sidx - r * QW;
     qrj[i] = (r << 8) | c;
+    qoff[i] = (unsigned)(r * p.Wq + c) * qC4 + qcl4;
   }
   // LDS element offsets of this thread's staging writes: plane (sc4 >> 3), row, 4 channels at (sc4 & 7) * 4
   const int wplane = (sc4 * CPT) >> 5, wcol = (sc4 * CPT) & 31;
@@ -1011,13 +1013,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const MsegWgrad
     }
     pmask = pbits;
     const int qy0 = S * spy - p.pad, qx0 = S * spx0 - p.pad;
+    const unsigned qbase = (unsigned)(qy0 * p.Wq + qx0) * qC4;       // scalar; wraps for the rows above the image (never loaded)
     unsigned okbits = 0u;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const bool qlive = spx + RP * i < QROWS;
       const int qy = qy0 + (qrj[i] >> 8), qx = qx0 + (qrj[i] & 255);
-      const bool ok = live & qvalid & qlive & (qy >= 0) & (qy < p.Hq) & (qx >= 0) & (qx < p.Wq);
-      const unsigned qo = (unsigned)(qy * p.Wq + qx) * qC4 + qcl4;
+      const bool ok = live & qvalid & qlive & ((unsigned)qy < (unsigned)p.Hq) & ((unsigned)qx < (unsigned)p.Wq);
+      const unsigned qo = qbase + qoff[i];
       rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, ok ? qo : OOB, 0, 0));
       okbits |= (unsigned)ok << i;
     }

@@ -1,15 +1,17 @@
 #!/bin/bash
-# GPU box: the same bench command against several builds of the library (MSEG_HIP_LIB), alternating, on ONE box
-# (boxes of the pool differ by up to 8 %, and one box drifts by 2-3 % between runs: compare medians of several rounds).
-# usage: tools/ab_lib.sh "<lib1> <lib2> ..." [bench args...]
-libs=$1; shift
+# GPU box: the same bench command under several settings, alternating, on ONE box (boxes of the pool differ by up to 8 %,
+# and one box drifts by 2-3 % between runs: compare medians of several rounds).  A setting is a build of the library
+# (a file name in microbeseg_amd/, exported as MSEG_HIP_LIB) or an environment assignment VAR=value.
+# usage: tools/ab_lib.sh "<setting1> <setting2> ..." [bench args...]
+sets=$1; shift
 for i in 1 2 3 4 5; do
-for lib in $libs; do
-MSEG_HIP_LIB=$PWD/microbeseg_amd/$lib python bench.py --steps 30 --warmup 5 --no-inference --no-cpu-baseline --no-kernel-timing --no-bf16-block "$@" 2>&1 | python -c "
+for s in $sets; do
+if [[ "$s" == *=* ]]; then pre="$s"; else pre="MSEG_HIP_LIB=$PWD/microbeseg_amd/$s"; fi
+env $pre python bench.py --steps 30 --warmup 5 --no-inference --no-cpu-baseline --no-kernel-timing --no-bf16-block "$@" 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('$lib', d['value'], d['ms_per_step'], flush=True)
+        d=json.loads(l); print('$s', d['value'], d['ms_per_step'], flush=True)
 "
 done; done | tee /tmp/ab.txt
 python - <<'P'
