@@ -49,6 +49,9 @@ def parse():
                     help="replay the step from a hipGraph (training/graph_step.py; 1 GPU, Adam; implies --no-kernel-timing): "
                          "for small batches / bf16, where the host cannot enqueue ~600 launches per step fast enough")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary inference (Mpixels/s) measurement")
+    ap.add_argument("--inference-only", action="store_true",
+                    help="(internal) run only the inference block and print {\"inference\": ...}: the default run measures it in "
+                         "a child process of its own, started before the parent touches the GPU")
     ap.add_argument("--infer-size", type=int, default=2048)
     ap.add_argument("--infer-frames", type=int, default=16, help="T of the 2D+t stack (SURVEY.md §8d: T = 16)")
     ap.add_argument("--no-bf16-block", action="store_true",
@@ -78,6 +81,27 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
+
+
+def inference_child(args):
+    """The inference block in a process of its own, run to completion BEFORE this process touches the GPU (a child of a
+    process without a HIP context, like launch_ranks).  Blocks that share one process disturb each other through the
+    allocator: the 2048^2 frames of the inference block and the batch-32 tensors of the training blocks leave each other an
+    address space cut into pieces, and whichever block ran second measured 4 % (bf16 training step, 40.63 vs 39.02 ms) to
+    9 % (bf16 product-path inference, 258 vs 283 Mpx/s) slower than on its own — same box, same kernels.  Returns the
+    block's dict, or None when the child failed (the caller then measures in-process)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--inference-only", "--arch", args.arch, "--act", args.act,
+           "--norm", args.norm, "--filters", str(args.filters[0]), str(args.filters[1]),
+           "--infer-size", str(args.infer_size), "--infer-frames", str(args.infer_frames), "--precision", args.precision]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line).get("inference")
+    except Exception:
+        pass
+    return None
 
 
 def synthetic_batch(batch, size, arch, seed, device):
@@ -625,6 +649,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if args.rehearse:
         return rehearse(args, world, rank)
+    want_inference = rank == 0 and world == 1 and not args.no_inference and args.arch == "DU"
+    inference = inference_child(args) if (want_inference and not args.inference_only) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # one rank per GPU.  MSEG_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N-rank path (ranks share the visible
@@ -645,19 +671,17 @@ def main():
             dist.init_process_group(backend)
 
     from microbeseg_amd import engine
+    if args.inference_only:
+        from microbeseg_amd.utils.unets import build_unet
+        engine.set_precision(args.precision)
+        torch.manual_seed(3)
+        net_i = build_unet(args.arch, args.act, "conv", args.norm, dev, 1, ch_out=1, filters=tuple(args.filters))
+        print(json.dumps({"inference": inference_metric(args, net_i, dev)}), flush=True)
+        return
     out, net = train_metric(args, dev, world, rank, timing=not args.no_kernel_timing)
     headline = workload_key(args) == {"batch": 32, "size": 256, "arch": "DU", "act": "relu", "norm": "bn",
                                       "filters": [64, 1024], "optimizer": "adam", "precision": "fp32"}
     del net
-    release()
-    if rank == 0 and world == 1 and not args.no_inference and args.arch == "DU":
-        # a freshly initialised network (fixed seed): the few optimisation steps above on random labels leave a network whose
-        # outputs are nearly constant, i.e. frames without seeds and a watershed with nothing to do
-        from microbeseg_amd.utils.unets import build_unet
-        torch.manual_seed(3)
-        net_i = build_unet(args.arch, args.act, "conv", args.norm, dev, 1, ch_out=1, filters=tuple(args.filters))
-        out["inference"] = inference_metric(args, net_i, dev)
-        del net_i
     release()
     if rank == 0 and world == 1 and headline and not args.no_bf16_block:
         # BASELINE configs[2] next to the fp32 headline, so that the driver's default run records it too
@@ -697,6 +721,19 @@ def main():
                 blk["graph_replay"] = {k: rep[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step")}
             out["secondary"][tag] = blk
         engine.set_precision(args.precision)
+    # (the inference block was measured first, in a child process of its own: inference_child)
+    if inference is not None:
+        out["inference"] = inference
+    elif want_inference:
+        # (in-process fallback)
+        # a freshly initialised network (fixed seed): the few optimisation steps above on random labels leave a network whose
+        # outputs are nearly constant, i.e. frames without seeds and a watershed with nothing to do
+        from microbeseg_amd.utils.unets import build_unet
+        torch.manual_seed(3)
+        net_i = build_unet(args.arch, args.act, "conv", args.norm, dev, 1, ch_out=1, filters=tuple(args.filters))
+        out["inference"] = inference_metric(args, net_i, dev)
+        del net_i
+    release()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, tuple(args.filters))
     if world > 1:
