@@ -225,10 +225,12 @@ size_t mseg_norm_workspace_bytes(int N, int HW, int C);
  * reduction / finalize launches (same results, bit for bit).  Default 0 (measured faster at batch 32); MSEG_NORM_TAILS in
  * the environment sets it for a process. */
 int mseg_norm_set_tails(int on);
-/* 1 (default): the small launch that reduces a pass's partial sums over the chunks also writes the per-channel results
- * (BatchNorm tables and running statistics, k1 / k2 / k3 + dgamma / dbeta, bias gradients) when there are <= 256 channels —
- * its last workgroup to arrive does what the finalize / column-sum launch did, same order, same bits; 0: always the
- * separate launch.  MSEG_NORM_FINISH in the environment sets it for a process. */
+/* How a BatchNorm pass's partial sums (and a bias gradient's) become the per-channel results.  2 (default): ONE launch
+ * without a hand-off between workgroups — a workgroup owns four channels and does the reduction over the chunks, the sum
+ * over the samples and the finalize arithmetic itself, in the order of the launches it replaces (any channel count);
+ * 1: the reduction launch whose last workgroup to arrive also finalizes (<= 256 channels, else two launches); 0: always
+ * the separate reduction and finalize / column-sum launches; -1: back to the default.  Same bits in every mode.
+ * MSEG_NORM_FINISH in the environment sets it for a process. */
 int mseg_norm_set_finish(int on);
 /* st: MSEG_ST_F32 / MSEG_ST_BF16 = storage of the activation tensors of the call (z, act_out; gy, dz, act_in below).  With
  * bf16 storage a thread owns 8 channels (C % 8 == 0) and the statistics are those of the values as stored.           */

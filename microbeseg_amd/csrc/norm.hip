@@ -679,6 +679,92 @@ __global__ __launch_bounds__(256) void norm_reduce_finish_kernel(const double* _
     norm_colsum_body(nc, g, t.colsum, threadIdx.x, 256);
 }
 
+// BatchNorm / bias gradients (per-channel results): from a pass's partial sums to the tables in ONE launch WITHOUT a hand-off
+// between workgroups.  A workgroup owns FOUR channels and does for them, in the order of the launches it replaces, what
+// norm_reduce_chunks_body (per sample: eight strided partial sums over the chunks, combined in order), the finalize bodies
+// (the samples summed in order) and norm_colsum_body do — same additions, same bits — with the per-sample sums handed on
+// through LDS instead of through `nc` + an arrival counter + an acquire (they are still written to `nc`, as before).  The
+// finishing reduction above spends ~10 us per launch on that hand-off (load, store, atomic, load again: four dependent
+// memory round trips); this is one round trip of independent loads, three barriers per statistic and N additions.
+// Threads: (sample lane nl = tid >> 5, chunk group kg = (tid >> 2) & 7, channel cl = tid & 3); any number of channels;
+// 256 threads (8 sample lanes) for up to 8 samples, else 1024 (32 lanes: the load phase is what the launch waits for).
+#define NORM_FB_CH 4
+#define NORM_FB_NB 64          // samples per round through LDS
+__global__ __launch_bounds__(1024) void norm_bn_finish_kernel(const double* __restrict__ part, double* __restrict__ nc,
+                                                             NormGeom g, int ns, const NormTail t) {
+  __shared__ double red[NORM_FB_NB][8][NORM_FB_CH];
+  __shared__ double tn[NORM_FB_NB][NORM_FB_CH];
+  __shared__ double tot[3][NORM_FB_CH];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, kg = (tid >> 2) & 7, nl = tid >> 5, nlanes = (int)blockDim.x >> 5;
+  const int c = blockIdx.x * NORM_FB_CH + cl;
+  const bool cok = c < g.C;
+  for (int sidx = 0; sidx < ns; ++sidx) {
+    double run = 0.0;                                  // threads 0..3: the sum over the samples, in order
+    for (int n0 = 0; n0 < g.N; n0 += NORM_FB_NB) {
+      const int nb = g.N - n0 < NORM_FB_NB ? g.N - n0 : NORM_FB_NB;
+#pragma unroll 2
+      for (int nn = nl; nn < nb; nn += nlanes) {
+        double acc = 0.0;
+        if (cok) {
+          const double* src = part + (((size_t)(n0 + nn) * g.chunks) * 3 + sidx) * g.C + c;
+          const size_t kstride = (size_t)3 * g.C;
+#pragma unroll 4
+          for (int k = kg; k < g.chunks; k += 8) acc += src[k * kstride];
+        }
+        red[nn][kg][cl] = acc;
+      }
+      __syncthreads();
+      {
+        const int nn = tid >> 2;                       // 64 samples x 4 channels
+        if (nn < nb) {
+          double s8 = 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s8 += red[nn][j][cl];
+          tn[nn][cl] = s8;
+          if (cok) nc[((size_t)sidx * g.N + n0 + nn) * g.C + c] = s8;
+        }
+      }
+      __syncthreads();
+      if (tid < NORM_FB_CH)
+        for (int nn = 0; nn < nb; ++nn) run += tn[nn][tid];
+      __syncthreads();
+    }
+    if (tid < NORM_FB_CH) tot[sidx][tid] = run;
+  }
+  if (tid >= NORM_FB_CH || !cok) return;               // (threads 0..3 read what they wrote themselves)
+  const double a0 = tot[0][tid], b0 = ns > 1 ? tot[1][tid] : 0.0;
+  if (t.kind == NORM_TAIL_BN_FWD) {
+    const double cnt = (double)g.N * g.HW;
+    const double mean = a0 / cnt;
+    double var = b0 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)t.eps);
+    const double ga = t.gamma ? (double)t.gamma[c] : 1.0, be = t.beta ? (double)t.beta[c] : 0.0;
+    t.scale[c] = (float)(ga * rstd);
+    t.shift[c] = (float)(be - mean * ga * rstd);
+    t.mean_out[c] = (float)mean;
+    t.rstd_out[c] = (float)rstd;
+    if (t.running_mean) {
+      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      t.running_mean[c] = (float)((1.0 - (double)t.momentum) * t.running_mean[c] + (double)t.momentum * mean);
+      t.running_var[c] = (float)((1.0 - (double)t.momentum) * t.running_var[c] + (double)t.momentum * unb);
+    }
+  } else if (t.kind == NORM_TAIL_BN_BWD) {             // a0 = sum gy, b0 = sum gy a
+    const double cnt = (double)g.N * g.HW;
+    const double mu = t.mean[c], r = t.rstd[c], ga = t.gamma ? (double)t.gamma[c] : 1.0;
+    const double sx = r * (b0 - mu * a0);              // sum gy * xhat
+    const double m1 = ga * a0 / cnt, m2 = ga * sx / cnt;
+    t.k1[c] = (float)(ga * r);
+    t.k2[c] = (float)(-r * r * m2);
+    t.k3[c] = (float)(-r * m1 + r * r * m2 * mu);
+    if (t.dgamma) t.dgamma[c] = (float)sx;
+    if (t.dbeta) t.dbeta[c] = (float)a0;
+  } else {
+    t.colsum[c] = (float)a0;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
                                       float* __restrict__ scale, float* __restrict__ shift) {
@@ -714,15 +800,27 @@ static inline unsigned nblocks(size_t n, unsigned cap = 1024u) {
 // bias gradients, <= 256 channels) instead of leaving them to a further launch; MSEG_NORM_FINISH=0: always two launches
 static int g_norm_finish = -1;
 extern "C" int mseg_norm_set_finish(int on) {
-  g_norm_finish = on ? 1 : 0;
+  g_norm_finish = on < 0 ? -1 : (on > 2 ? 2 : on);     // 2: norm_bn_finish_kernel (any channel count); -1: the default
   return MSEG_OK;
 }
-static bool norm_finish_fits(int C) {
+static int norm_finish_mode() {
   if (g_norm_finish < 0) {
     const char* e = getenv("MSEG_NORM_FINISH");
-    g_norm_finish = e ? (atoi(e) != 0) : 1;
+    g_norm_finish = e ? atoi(e) : 2;
+    if (g_norm_finish < 0 || g_norm_finish > 2) g_norm_finish = 2;
   }
-  return g_norm_finish && C <= 256;
+  return g_norm_finish;
+}
+static bool norm_finish_fits(int C) { return norm_finish_mode() == 2 || (norm_finish_mode() == 1 && C <= 256); }
+// the per-channel results of a BatchNorm pass / a bias gradient from the partial sums: one launch (see the two kernels)
+static void norm_launch_finish(const double* part, double* nc, const NormGeom& g, int ns, const NormTail& tf, int N, int C,
+                               hipStream_t st) {
+  if (norm_finish_mode() == 2)
+    hipLaunchKernelGGL(norm_bn_finish_kernel, dim3((unsigned)((C + NORM_FB_CH - 1) / NORM_FB_CH)), dim3(N > 8 ? 1024 : 256), 0,
+                       st, part, nc, g, ns, tf);
+  else
+    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)ns * N * C * 8, 4096u)), dim3(256), 0, st, part, nc, g,
+                       ns, tf);
 }
 static int g_norm_tails = -1;          // -1: not set yet (MSEG_NORM_TAILS in the environment, else the default below)
 // Test / ablation hook: 1 = the last workgroups of a pass finish the reductions in the kernel, 0 = every pass is followed by
@@ -764,8 +862,7 @@ extern "C" int mseg_norm_stats(const void* z, int N, int HW, int C, int st_, int
   if (t.kind != NORM_TAIL_NONE) return MSEG_OK;
   if (norm == MSEG_NORM_BN && norm_finish_fits(C)) {
     t.kind = NORM_TAIL_BN_FWD;
-    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
-                       (const double*)part, nc, g, 2, t);
+    norm_launch_finish((const double*)part, nc, g, 2, t, N, C, st);
     MSEG_LAUNCH_CHECK();
     return MSEG_OK;
   }
@@ -877,8 +974,7 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   if (t.kind == NORM_TAIL_NONE && norm == MSEG_NORM_BN && norm_finish_fits(C)) {
     NormTail tf = t;
     tf.kind = NORM_TAIL_BN_BWD;
-    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
-                       (const double*)part, nc, g, 2, tf);
+    norm_launch_finish((const double*)part, nc, g, 2, tf, N, C, st);
     MSEG_LAUNCH_CHECK();
   } else if (t.kind == NORM_TAIL_NONE) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)2 * N * C * 8, 4096u)), dim3(256), 0, st,
@@ -898,8 +994,7 @@ extern "C" int mseg_norm_bwd(const void* gy, const void* z, int N, int HW, int C
   if (dbias && t2.kind == NORM_TAIL_NONE && norm_finish_fits(C)) {
     NormTail tf = t2;
     tf.kind = NORM_TAIL_COLSUM;
-    hipLaunchKernelGGL(norm_reduce_finish_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,
-                       (const double*)part2, nc, g, 1, tf);
+    norm_launch_finish((const double*)part2, nc, g, 1, tf, N, C, st);
     MSEG_LAUNCH_CHECK();
   } else if (dbias && t2.kind == NORM_TAIL_NONE) {
     hipLaunchKernelGGL(norm_reduce_chunks_kernel, dim3(nblocks((size_t)N * C * 8, 4096u)), dim3(256), 0, st,

@@ -272,9 +272,10 @@ def test_norm_forward_backward(eng, norm, act, N, Cc, H, W):
 @pytest.mark.parametrize("norm", ["bn", "gn", "in"])
 @pytest.mark.parametrize("N,Cc,H,W", [(4, 64, 96, 96), (9, 256, 40, 40), (32, 1024, 12, 10), (2, 72, 33, 31), (33, 128, 64, 64)])
 def test_norm_tails_equal_separate_launches(eng, st, norm, N, Cc, H, W):
-    """Three ways to get from a pass's partial sums to the tables: separate reduction + finalize launches; the reduction
-    launch whose last workgroup also finalizes (mseg_norm_set_finish(1), the default, <= 256 channels); the last workgroups
-    of the pass itself (mseg_norm_set_tails(1)).  Every output — tables, saved statistics, running statistics, dz, dgamma,
+    """Four ways to get from a pass's partial sums to the tables: separate reduction + finalize launches; the reduction
+    launch whose last workgroup also finalizes (mseg_norm_set_finish(1), <= 256 channels); one launch in which a workgroup
+    does all of it for four channels (mseg_norm_set_finish(2), the default); the last workgroups of the pass itself
+    (mseg_norm_set_tails(1)).  Every output — tables, saved statistics, running statistics, dz, dgamma,
     dbeta, dbias — is BIT-identical between them, call after call on one workspace (the arrival counters return to zero),
     for one to many chunks, channel slices and samples."""
     from microbeseg_amd import _lib
@@ -290,7 +291,7 @@ def test_norm_tails_equal_separate_launches(eng, st, norm, N, Cc, H, W):
     has_aff = norm != "in"
     ws = eng.Workspace(torch.device("cuda"))
     results = []
-    for tails, finish in ((0, 0), (0, 1), (1, 0), (0, 1)):
+    for tails, finish in ((0, 0), (0, 1), (1, 0), (0, 1), (0, 2), (0, 2)):
         assert lib.mseg_norm_set_tails(tails) == 0 and lib.mseg_norm_set_finish(finish) == 0
         try:
             node = eng.Node(z, N, H, W, Cc)
@@ -309,12 +310,14 @@ def test_norm_tails_equal_separate_launches(eng, st, norm, N, Cc, H, W):
             results.append([o.clone() for o in out])
         finally:
             lib.mseg_norm_set_tails(0)
-            lib.mseg_norm_set_finish(1)
-    for k, (a, b, c, d) in enumerate(zip(*results)):
+            lib.mseg_norm_set_finish(-1)
+    for k, (a, b, c, d, e, f) in enumerate(zip(*results)):
         assert torch.isfinite(a).all(), k
         assert torch.equal(a, b), f"output {k}: the finishing reduction differs from the separate launches"
         assert torch.equal(a, c), f"output {k}: tails differ from the separate launches"
         assert torch.equal(a, d), f"output {k}: second call on the same workspace differs"
+        assert torch.equal(a, e), f"output {k}: the four-channels-per-workgroup launch differs from the separate launches"
+        assert torch.equal(a, f), f"output {k}: its second call differs"
     # the counters are back at zero
     head = ws.buf["norm"][:65536].view(torch.int32)
     assert int(head.abs().max().item()) == 0
