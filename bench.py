@@ -525,12 +525,17 @@ def train_metric(args, dev, world, rank, timing=True):
     prof = engine.KernelTimer() if timing else None
     engine.set_kernel_timer(None if two_pass else prof)
     fence()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     t_host = time.perf_counter() - t0        # the host's share: all K steps enqueued (it may have waited for queue space)
     fence()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree calls of the caching allocator inside the timed region (each one synchronises the device: a
+    # steady-state step makes none)
+    alloc_calls = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     engine.set_kernel_timer(None)
     dt_bracketed = None
     if two_pass:
@@ -576,6 +581,7 @@ def train_metric(args, dev, world, rank, timing=True):
                    "launch": "hipGraph replay" if graph else "eager"},
         "per_gpu_value": round(value / world, 3),
         "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
+        "allocator_calls_in_timed_region": alloc_calls,
     }
     if world > 1:
         out["config"]["collective"] = "RCCL all-reduce of fp32 gradient buckets, overlapped with the backward"
