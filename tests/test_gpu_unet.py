@@ -238,6 +238,53 @@ def test_fused_adam_equals_torch_adam(dev):
             assert rel_err(sb[key].cpu(), sa[key].cpu()) < 2e-6, key
 
 
+def test_fused_adam_load_state_dict(dev):
+    """FusedAdam.load_state_dict: a state dict of torch.optim.Adam — and its own — is taken over INTO the flat
+    arenas (the state tensors stay views of them), and the kernel reads the learning rate of the param_groups that
+    load_state_dict installed: after a resume, a scheduler's change of param_groups[0]['lr'] reaches the next step."""
+    from microbeseg_amd.training.optim import FusedAdam
+    g = torch.Generator().manual_seed(22)
+    shapes = [(32, 16, 3, 3), (32,), (5,), (9, 4, 2, 2)]
+    init = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    oa = torch.optim.Adam(pa, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)
+    ob = FusedAdam(pb, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=True)     # another lr on purpose
+
+    def both_step():
+        grads = [torch.randn(s, generator=g) * 0.05 for s in shapes]
+        ob.zero_grad()
+        for a, b, gr in zip(pa, pb, grads):
+            a.grad = gr.clone().to(dev)
+            b.grad.copy_(gr.to(dev))
+        oa.step()
+        ob.step()
+
+    for _ in range(3):                                   # torch's Adam runs ahead; FusedAdam follows with a wrong lr
+        grads = [torch.randn(s, generator=g) * 0.05 for s in shapes]
+        for a, gr in zip(pa, grads):
+            a.grad = gr.clone().to(dev)
+        oa.step()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    arena_ptrs = [ob.state[b]["exp_avg"].data_ptr() for b in pb]
+    ob.load_state_dict(oa.state_dict())                  # moments, step counters AND lr = 8e-4 come from torch's optimizer
+    assert [ob.state[b]["exp_avg"].data_ptr() for b in pb] == arena_ptrs, "the moments must stay views of the arenas"
+    assert ob.param_groups[0]["lr"] == 8e-4
+    both_step()
+    for a, b in zip(pa, pb):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6
+    for o in (oa, ob):
+        o.param_groups[0]["lr"] = 1e-4                   # a scheduler edits the groups load_state_dict installed
+    both_step()
+    ob.load_state_dict(ob.state_dict())                  # its own round trip
+    both_step()
+    for a, b in zip(pa, pb):
+        assert rel_err(b.detach().cpu(), a.detach().cpu()) < 2e-6
+        assert int(oa.state[a]["step"]) == ob.state[b]["step"] == 6
+
+
 def test_ranger_multi_tensor_step(dev):
     """Ranger.step() updates all CUDA tensors of a group with mseg_ranger_step_multi (48 tensors per launch): bit-identical
     to mseg_ranger_step called per tensor, and the optimizer follows its own torch path (CPU parameters) over 14 steps
