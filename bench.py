@@ -357,6 +357,52 @@ def inference_metric(args, net, dev):
         untrained = {"ms_per_frame": round(1e3 * dt2 / 2, 1), "instances_frame0": int(m2[0].max()), "frames": 2,
                      "note": "no hook: the untrained network's own output, thresholds at its 85 % / 96 % quantiles"}
         del worker
+    # ---- the same product path for the boundary method (U-Net, 3 classes): its post-processing is ONE wavefront busy for
+    # ~45 ms per frame, so infer_stack keeps the frames of a stack in flight side by side on InferWorker.BOUNDARY_STREAMS
+    # streams; `streams_1` is the same stack with one frame at a time -------------------------------------------------------
+    boundary_stack = None
+    try:
+        from microbeseg_amd.utils.unets import build_unet
+        torch.manual_seed(5)
+        net_u = build_unet("U", args.act, "conv", args.norm, dev, 1, ch_out=3, filters=tuple(args.filters))
+        logits_s = torch.log(probs.permute(2, 0, 1)[None].contiguous() + 1e-6)      # (1, 3, S, S): the synthetic classes
+        lcache = {}
+
+        def hook_u(pred):
+            shp = tuple(pred.shape)
+            if shp not in lcache:
+                ph, pw = shp[2] - S, shp[3] - S
+                lcache[shp] = torch.nn.functional.pad(logits_s, (pw, 0, ph, 0), value=0.0)
+            return lcache[shp]
+        with tempfile.TemporaryDirectory() as tmp:
+            base = os.path.join(tmp, "boundary_model_00")
+            torch.save(net_u.state_dict(), base + ".pth")
+            with open(base + ".json", "w") as f:
+                _json.dump({"architecture": ["U", "conv", args.act, args.norm, list(args.filters)], "label_type": "boundary"}, f)
+            wu = InferWorker(model=base, device=str(dev))
+            wu.prediction_hook = hook_u
+            boundary_stack = {"unit": "Mpx/s", "frames": T, "streams": int(wu.BOUNDARY_STREAMS)}
+            for prec in ("fp32", "bf16"):
+                wu.precision = prec
+                for ns in (wu.BOUNDARY_STREAMS, 1):
+                    wu.BOUNDARY_STREAMS = ns
+                    wu.infer_stack(stack[:max(2, ns)])       # warm-up: every stream's workspace exists
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    mu = wu.infer_stack(stack)
+                    dtu = time.perf_counter() - t0
+                    key = prec if ns > 1 else prec + "_streams_1"
+                    boundary_stack[key] = {"value": round(T * S * S / dtu / 1e6, 2), "ms_per_frame": round(1e3 * dtu / T, 2),
+                                           "instances_frame0": int(mu[0].max())}
+                wu.BOUNDARY_STREAMS = boundary_stack["streams"]
+                with torch.no_grad():                    # one frame alone, on the main stream
+                    single = wu._postprocess(logits_s, [0, 0]).cpu().numpy().view(np.uint16)
+                boundary_stack[prec]["masks_equal_single_call"] = bool(np.array_equal(mu[0], single) and
+                                                                       np.array_equal(mu[T - 1], single))
+            del wu
+        del net_u
+    except Exception as err:                               # (secondary measurement: never costs the headline line)
+        boundary_stack = {"error": repr(err)[:200]}
     net.train()
     main = product[args.precision]
     return {"metric": "inference Mpixels/sec incl. watershed", "value": main["value"],
@@ -371,6 +417,7 @@ def inference_metric(args, net, dev):
             "bf16": product["bf16"], "fp32": product["fp32"], "untrained_predictions": untrained,
             "postproc_Mpx_s": round(S * S / t_pp / 1e3, 1), "instances": int(n_inst), "postproc_status": int(status),
             "labels_bit_exact_vs_oracle": exact,
+            "boundary_stack": boundary_stack,
             "boundary_postproc": {"value": round(S * S / t_bpp / 1e3, 1), "unit": "Mpx/s", "ms": round(t_bpp, 2),
                                   "instances": int(bn), "status": int(bs), "labels_bit_exact_vs_oracle": exact_b},
             "cpu_postproc": {"value": round(S * S / t_cpu / 1e6, 2), "unit": "Mpx/s", "cores": 1, "kind": "port",

@@ -14,6 +14,22 @@ import torch
 from .. import _lib
 
 _ws_cache = {}
+_slot = [0]
+
+
+class workspace_slot:
+    """``with workspace_slot(i):`` the post-processing calls inside use workspace i (default 0) — for callers that keep
+    several calls in flight on different streams; a slot must not be reused before its previous call has finished"""
+
+    def __init__(self, slot):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        self.prev, _slot[0] = _slot[0], self.slot
+
+    def __exit__(self, *exc):
+        _slot[0] = self.prev
+        return False
 
 
 def _stream():
@@ -34,7 +50,9 @@ def _workspace(dev, H, W):
     need = lib.mseg_postproc_workspace_bytes(H, W)
     if need == 0:
         raise RuntimeError(f"unsupported frame size {H}x{W}")
-    key = str(dev)
+    # one workspace per (device, slot): calls that may be in flight together on different streams (frames of a stack,
+    # infer_stack) name different slots and so never share scratch memory
+    key = (str(dev), _slot[0])
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
