@@ -190,7 +190,13 @@ class InferWorker(QObject):
         nside = self.BOUNDARY_STREAMS if boundary else 1
         # (fresh streams per call, as before: HIP spreads new streams over its hardware queues, and a long-lived side stream
         # that came to share a queue with the main or the copy stream cost the distance path 14 % — 257 vs 299 Mpx/s)
-        sides = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
+        # Boundary method: HIGH-priority streams.  HIP multiplexes streams onto a few hardware queues per priority level, and
+        # kernels of streams that share a queue run one after the other: at the default priority a 45-ms flood sat in front of
+        # the network's kernels whenever its stream shared the main stream's queue (37 ms per frame, bf16 network, measured
+        # in a process of its own); high-priority streams have queues of their own (21 ms), and one wavefront takes nothing
+        # away from the network whatever its priority.
+        sides = [torch.cuda.Stream(device=self.device, priority=-1) if boundary else torch.cuda.Stream(device=self.device)
+                 for _ in range(nside)]
         in_flight = nside + 1
         pending = []      # (frame index, pinned host mask, event on the side stream)
 
