@@ -357,9 +357,9 @@ def inference_metric(args, net, dev):
         untrained = {"ms_per_frame": round(1e3 * dt2 / 2, 1), "instances_frame0": int(m2[0].max()), "frames": 2,
                      "note": "no hook: the untrained network's own output, thresholds at its 85 % / 96 % quantiles"}
         del worker
-    # ---- the same product path for the boundary method (U-Net, 3 classes): its post-processing is ONE wavefront busy for
-    # ~45 ms per frame, so infer_stack keeps the frames of a stack in flight side by side on InferWorker.BOUNDARY_STREAMS
-    # streams; `streams_1` is the same stack with one frame at a time -------------------------------------------------------
+    # ---- the same product path for the boundary method (U-Net, 3 classes): its flood is ONE wavefront busy for ~45 ms per
+    # frame, so infer_stack collects InferWorker.BOUNDARY_BATCH frames and launches their floods together (one workgroup per
+    # frame); `*_batch_1` is the same stack with one frame per launch ------------------------------------------------------
     boundary_stack = None
     try:
         from microbeseg_amd.utils.unets import build_unet
@@ -381,20 +381,20 @@ def inference_metric(args, net, dev):
                 _json.dump({"architecture": ["U", "conv", args.act, args.norm, list(args.filters)], "label_type": "boundary"}, f)
             wu = InferWorker(model=base, device=str(dev))
             wu.prediction_hook = hook_u
-            boundary_stack = {"unit": "Mpx/s", "frames": T, "streams": int(wu.BOUNDARY_STREAMS)}
+            boundary_stack = {"unit": "Mpx/s", "frames": T, "frames_per_flood_launch": int(wu.BOUNDARY_BATCH)}
             for prec in ("fp32", "bf16"):
                 wu.precision = prec
-                for ns in (wu.BOUNDARY_STREAMS, 1):
-                    wu.BOUNDARY_STREAMS = ns
-                    wu.infer_stack(stack[:max(2, ns)])       # warm-up: every stream's workspace exists
+                for ns in (wu.BOUNDARY_BATCH, 1):
+                    wu.BOUNDARY_BATCH = ns
+                    wu.infer_stack(stack[:2 * ns])           # warm-up: both groups' workspaces exist
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     mu = wu.infer_stack(stack)
                     dtu = time.perf_counter() - t0
-                    key = prec if ns > 1 else prec + "_streams_1"
+                    key = prec if ns > 1 else prec + "_batch_1"
                     boundary_stack[key] = {"value": round(T * S * S / dtu / 1e6, 2), "ms_per_frame": round(1e3 * dtu / T, 2),
                                            "instances_frame0": int(mu[0].max())}
-                wu.BOUNDARY_STREAMS = boundary_stack["streams"]
+                wu.BOUNDARY_BATCH = boundary_stack["frames_per_flood_launch"]
                 with torch.no_grad():                    # one frame alone, on the main stream
                     single = wu._postprocess(logits_s, [0, 0]).cpu().numpy().view(np.uint16)
                 boundary_stack[prec]["masks_equal_single_call"] = bool(np.array_equal(mu[0], single) and

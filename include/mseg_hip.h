@@ -372,6 +372,15 @@ int mseg_distance_postprocess(const float* border, const float* cell, int H, int
                               void* ws, size_t ws_bytes, void* stream);
 int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, uint16_t* labels, int32_t* n_instances_dev,
                               int32_t* status_dev, void* ws, size_t ws_bytes, void* stream);
+/* The same in three calls, so that the frames of a stack (infer.py:250-259: a 2D+t stack, frame by frame) can be in flight
+ * together: _pre per frame on its OWN workspace (thresholds, components, marker list), ONE _flood_batch for up to 8 frames
+ * — the boundary method's flood is one wavefront busy for ~45 ms per 2048 x 2048 frame, a latency and not a load, and the
+ * batch launch runs one workgroup per frame — then _post per frame.  ws_list: B host pointers to the frames' device
+ * workspaces.  pre + flood_batch(B = 1) + post makes the launches of mseg_boundary_postprocess: same labels bit for bit. */
+int mseg_boundary_postprocess_pre(const float* probs_hwc, int H, int W, void* ws, size_t ws_bytes, void* stream);
+int mseg_boundary_flood_batch(void* const* ws_list, int B, int H, int W, void* stream);
+int mseg_boundary_postprocess_post(int H, int W, uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev, void* ws,
+                                   size_t ws_bytes, void* stream);
 
 /* Threshold sweep of the evaluation (EvalWorker.inference, src/evaluation/eval.py:127-131,397-409: one
  * distance_postprocessing per (th_cell, th_seed) pair on the same prediction).  The smoothed cell map is computed once;

@@ -122,6 +122,9 @@ SIGNATURES = {
     "mseg_postproc_set_const_stream": (_I, [_I]),
     "mseg_distance_postprocess": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_boundary_postprocess": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "mseg_boundary_postprocess_pre": (_I, [_P, _I, _I, _P, _SZ, _P]),
+    "mseg_boundary_flood_batch": (_I, [C.POINTER(C.c_void_p), _I, _I, _I, _P]),
+    "mseg_boundary_postprocess_post": (_I, [_I, _I, _P, _P, _P, _P, _SZ, _P]),
     "mseg_distance_postprocess_sweep": (_I, [_P, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _I, _P, _P,
                                              _P, _P, _SZ, _P]),
     "mseg_aug_u16_to_f32": (_I, [_P, _P, _SZ, _P]),

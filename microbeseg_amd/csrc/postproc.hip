@@ -990,7 +990,8 @@ __global__ void pp_flood_const_list_kernel(const int32_t* __restrict__ flag, con
 // fetches the entry and the neighbour state of the u-th predicted pop — retires the leading pops that neither push a
 // neighbour nor move a pushed (age > 0) entry to the root in one step, and lets lane 0 execute the first pop that does
 // with the reference code.  Same pop / push sequence as the serial flood, ~1/50 of its dependent memory round trips.
-__global__ __launch_bounds__(64) void pp_flood_const_serial_kernel(
+// (bodies as device functions: each has a one-frame launch and a launch with one workgroup per FRAME of a batch, below)
+__device__ __forceinline__ void pp_flood_const_serial_body(
     const float* __restrict__ img, const uint8_t* __restrict__ mask, unsigned long long* __restrict__ hkey,
     uint32_t* __restrict__ hidx, uint32_t* __restrict__ queue, int32_t* __restrict__ out, int H, int W,
     int32_t* __restrict__ counters) {
@@ -1195,7 +1196,7 @@ __device__ __forceinline__ int ppc_post_next(int c, int zn) {
 __device__ __forceinline__ int pps_writelane(int val, int lane, int old) {
   return (int)(threadIdx.x & 63u) == lane ? val : old;
 }
-__global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
+__device__ __forceinline__ void pp_flood_const_stream_body(
     const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
     const uint32_t* __restrict__ PE, const uint32_t* __restrict__ PPOS, uint32_t* __restrict__ PFL,
     uint32_t* __restrict__ TPK, const uint32_t* __restrict__ MPOS, const int32_t* __restrict__ isMarker,
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
 }
 
 // kernel 3/3: breadth-first search in queue order, level by level
-__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_bfs_kernel(
+__device__ __forceinline__ void pp_flood_const_bfs_body(
     const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
     int32_t* __restrict__ out, int H, int W, const int32_t* __restrict__ counters) {
   __shared__ int sh_scan[PPC_THREADS];
@@ -1526,6 +1527,49 @@ __global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_bfs_kernel(
 #undef PPC_LD
 }
 
+// ---- launches of the three bodies: one frame, or one workgroup per FRAME of a batch ------------------------------------------
+// The marker phase is one wavefront busy for ~45 ms per 2048^2 frame — a latency, not a load.  Frames of a stack are
+// independent, so mseg_boundary_flood_batch puts up to PP_BATCH_MAX of them into ONE launch of each body (blockIdx.x = frame,
+// every frame with its own workspace): eight floods take the time of one, whatever HIP does with streams and queues.
+#define PP_BATCH_MAX 8
+struct PPConstFrame {
+  const float* img; const uint8_t* mask; unsigned long long* hkey; uint32_t* hidx; uint32_t* clist; uint32_t* hoff;
+  uint32_t *bymin, *bymax, *bxmin, *bxmax, *carea; const int32_t* flag; int32_t* out; int32_t* counters;
+};
+struct PPConstBatch { PPConstFrame f[PP_BATCH_MAX]; };
+
+__global__ __launch_bounds__(64) void pp_flood_const_stream_kernel(
+    const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
+    const uint32_t* __restrict__ PE, const uint32_t* __restrict__ PPOS, uint32_t* __restrict__ PFL,
+    uint32_t* __restrict__ TPK, const uint32_t* __restrict__ MPOS, const int32_t* __restrict__ isMarker,
+    uint32_t* __restrict__ JB, int32_t* __restrict__ out, int H, int W, int32_t* __restrict__ counters) {
+  pp_flood_const_stream_body(mask, queue, claim, PE, PPOS, PFL, TPK, MPOS, isMarker, JB, out, H, W, counters);
+}
+__global__ __launch_bounds__(64) void pp_flood_const_serial_kernel(
+    const float* __restrict__ img, const uint8_t* __restrict__ mask, unsigned long long* __restrict__ hkey,
+    uint32_t* __restrict__ hidx, uint32_t* __restrict__ queue, int32_t* __restrict__ out, int H, int W,
+    int32_t* __restrict__ counters) {
+  pp_flood_const_serial_body(img, mask, hkey, hidx, queue, out, H, W, counters);
+}
+__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_bfs_kernel(
+    const uint8_t* __restrict__ mask, uint32_t* __restrict__ queue, uint32_t* __restrict__ claim,
+    int32_t* __restrict__ out, int H, int W, const int32_t* __restrict__ counters) {
+  pp_flood_const_bfs_body(mask, queue, claim, out, H, W, counters);
+}
+__global__ __launch_bounds__(64) void pp_flood_const_stream_multi_kernel(const PPConstBatch b, int H, int W) {
+  const PPConstFrame& p = b.f[blockIdx.x];
+  pp_flood_const_stream_body(p.mask, p.clist, p.hoff, p.bymin, p.bymax, p.bxmin, p.bxmax, p.carea, p.flag, p.hidx, p.out, H, W,
+                             p.counters);
+}
+__global__ __launch_bounds__(64) void pp_flood_const_serial_multi_kernel(const PPConstBatch b, int H, int W) {
+  const PPConstFrame& p = b.f[blockIdx.x];
+  pp_flood_const_serial_body(p.img, p.mask, p.hkey, p.hidx, p.clist, p.out, H, W, p.counters);
+}
+__global__ __launch_bounds__(PPC_THREADS) void pp_flood_const_bfs_multi_kernel(const PPConstBatch b, int H, int W) {
+  const PPConstFrame& p = b.f[blockIdx.x];
+  pp_flood_const_bfs_body(p.mask, p.clist, p.hoff, p.out, H, W, p.counters);
+}
+
 __global__ void pp_finalize_kernel(const int32_t* __restrict__ out, uint16_t* __restrict__ labels, size_t n,
                                    const int32_t* __restrict__ counters, int32_t* __restrict__ n_inst,
                                    int32_t* __restrict__ status) {
@@ -1551,10 +1595,19 @@ static void pp_gauss_weights(double w[3]) {
 }
 
 // shared tail: seeds (binary) + mask + image -> labels
+// phase 0: everything; 1 (constant image only): up to the launches of the three constant-image flood bodies — which
+// mseg_boundary_flood_batch then makes for several frames at once; 2: what follows them
 static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int distance_rule, int col_major,
-                              int force_serial, uint16_t* labels, int32_t* n_inst, int32_t* status, hipStream_t st) {
+                              int force_serial, uint16_t* labels, int32_t* n_inst, int32_t* status, hipStream_t st,
+                              int phase = 0) {
   const size_t n = (size_t)H * W;
   const unsigned nb = pp_blocks(n);
+  if (phase == 2) {
+    hipLaunchKernelGGL(pp_finalize_kernel, dim3(nb), dim3(PP_BLOCK), 0, st, (const int32_t*)w.out, labels, n,
+                       (const int32_t*)w.counters, n_inst, status);
+    MSEG_LAUNCH_CHECK();
+    return MSEG_OK;
+  }
   (void)hipMemsetAsync(w.counters, 0, sizeof(int32_t) * C_COUNT, st);
   if (force_serial) hipLaunchKernelGGL(pp_fill_kernel, dim3(1), dim3(PP_BLOCK), 0, st, w.counters + C_SERIAL, 1, (size_t)1);
   (void)hipMemsetAsync(w.area, 0, sizeof(int32_t) * n, st);
@@ -1616,6 +1669,10 @@ static int pp_seeds_to_labels(const PPWs& w, const float* img, int H, int W, int
     hipLaunchKernelGGL(pp_flood_const_orders_kernel, dim3(256 * 4), dim3(256), 0, st, img, (const uint8_t*)w.mask,
                        (const int32_t*)w.out, (const uint32_t*)w.clist, H, W, (uint32_t*)w.bymin, (uint32_t*)w.bymax,
                        (uint32_t*)w.bxmin, (uint32_t*)w.bxmax, (uint32_t*)w.carea, (uint32_t*)w.hidx, w.counters);
+    if (phase == 1) {
+      MSEG_LAUNCH_CHECK();
+      return MSEG_OK;
+    }
     hipLaunchKernelGGL(pp_flood_const_stream_kernel, dim3(1), dim3(64), 0, st, (const uint8_t*)w.mask, (uint32_t*)w.clist,
                        (uint32_t*)w.hoff, (const uint32_t*)w.bymin, (const uint32_t*)w.bymax, (uint32_t*)w.bxmin,
                        (uint32_t*)w.bxmax, (const uint32_t*)w.carea, (const int32_t*)w.flag, (uint32_t*)w.hidx, w.out, H, W,
@@ -1728,6 +1785,58 @@ extern "C" int mseg_boundary_postprocess(const float* probs_hwc, int H, int W, u
   MSEG_LAUNCH_CHECK();
   // constant image: every key ties -> the order is the global heap's; go straight to the exact serial flood
   return pp_seeds_to_labels(w, w.tmp, H, W, 0, 0, 1, labels, n_instances_dev, status_dev, st);
+}
+
+// The same in three calls, for several frames in flight (InferWorker.infer_stack): _pre (thresholds, components, marker list,
+// preorder ranks) per frame on its own workspace, ONE _flood_batch for up to 8 frames (one workgroup per frame), _post per
+// frame.  pre + flood_batch(B = 1) + post == mseg_boundary_postprocess, launch for launch.
+extern "C" int mseg_boundary_postprocess_pre(const float* probs_hwc, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  if (!probs_hwc || !ws || H <= 0 || W <= 0) return MSEG_EINVAL;
+  const size_t need = mseg_postproc_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  PPWs w;
+  pp_carve(&w, ws, H, W);
+  const size_t n = (size_t)H * W;
+  hipLaunchKernelGGL(pp_boundary_thresh_kernel, dim3(pp_blocks(n)), dim3(PP_BLOCK), 0, st, probs_hwc, n, w.mask,
+                     w.seedb, w.tmp);
+  MSEG_LAUNCH_CHECK();
+  return pp_seeds_to_labels(w, w.tmp, H, W, 0, 0, 1, nullptr, nullptr, nullptr, st, 1);
+}
+
+extern "C" int mseg_boundary_flood_batch(void* const* ws_list, int B, int H, int W, void* stream) {
+  if (!ws_list || B <= 0 || B > PP_BATCH_MAX || H <= 0 || W <= 0) return MSEG_EINVAL;
+  if (mseg_postproc_workspace_bytes(H, W) == 0) return MSEG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PPConstBatch b;
+  for (int i = 0; i < PP_BATCH_MAX; ++i) {
+    void* base = ws_list[i < B ? i : 0];
+    if (!base) return MSEG_EINVAL;
+    PPWs w;
+    pp_carve(&w, base, H, W);
+    PPConstFrame& f = b.f[i];
+    f.img = w.tmp; f.mask = (const uint8_t*)w.mask; f.hkey = w.hkey; f.hidx = (uint32_t*)w.hidx; f.clist = (uint32_t*)w.clist;
+    f.hoff = (uint32_t*)w.hoff; f.bymin = (uint32_t*)w.bymin; f.bymax = (uint32_t*)w.bymax; f.bxmin = (uint32_t*)w.bxmin;
+    f.bxmax = (uint32_t*)w.bxmax; f.carea = (uint32_t*)w.carea; f.flag = (const int32_t*)w.flag; f.out = w.out;
+    f.counters = w.counters;
+  }
+  hipLaunchKernelGGL(pp_flood_const_stream_multi_kernel, dim3(B), dim3(64), 0, st, b, H, W);
+  hipLaunchKernelGGL(pp_flood_const_serial_multi_kernel, dim3(B), dim3(64), 0, st, b, H, W);
+  hipLaunchKernelGGL(pp_flood_const_bfs_multi_kernel, dim3(B), dim3(PPC_THREADS), 0, st, b, H, W);
+  MSEG_LAUNCH_CHECK();
+  return MSEG_OK;
+}
+
+extern "C" int mseg_boundary_postprocess_post(int H, int W, uint16_t* labels, int32_t* n_instances_dev, int32_t* status_dev,
+                                              void* ws, size_t ws_bytes, void* stream) {
+  if (!labels || !ws || H <= 0 || W <= 0) return MSEG_EINVAL;
+  const size_t need = mseg_postproc_workspace_bytes(H, W);
+  if (need == 0) return MSEG_EINVAL;
+  if (ws_bytes < need) return MSEG_EWORKSPACE;
+  PPWs w;
+  pp_carve(&w, ws, H, W);
+  return pp_seeds_to_labels(w, w.tmp, H, W, 0, 0, 1, labels, n_instances_dev, status_dev, (hipStream_t)stream, 2);
 }
 
 // =====================================================================================================================

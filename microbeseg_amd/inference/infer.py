@@ -65,7 +65,7 @@ class InferWorker(QObject):
     # post-processing.  bench.py uses it to hand the watershed realistic distance maps: an UNTRAINED network (there are no
     # checkpoints offline) predicts one confluent blob, whose flood is a single sequential component.
     prediction_hook = None
-    BOUNDARY_STREAMS = 8    # infer_stack, boundary method: frames whose post-processing may be in flight side by side
+    BOUNDARY_BATCH = 8      # infer_stack, boundary method: frames whose floods share one launch (1..8)
 
     def __init__(self, img_id_list=None, inference_path=None, omero_username=None, omero_password=None, omero_host=None,
                  omero_port=None, group_id=None,
@@ -151,13 +151,19 @@ class InferWorker(QObject):
             labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1], th_cell=self.ths[0],
                                                              col_major_ids=True)
         else:
-            logits = pred.contiguous()
-            _, _, hp, wp = logits.shape
-            probs = torch.empty((hp - pads[0], wp - pads[1], 3), dtype=torch.float32, device=logits.device)
-            _lib.check(lib.mseg_softmax3_hwc(logits.data_ptr(), hp, wp, int(pads[0]), int(pads[1]), probs.data_ptr(),
-                                             torch.cuda.current_stream().cuda_stream), "softmax3_hwc")
-            labels, _, _ = pp.boundary_postprocessing_device(probs)
+            labels, _, _ = pp.boundary_postprocessing_device(self._softmax_hwc(pred, pads))
         return labels
+
+    @staticmethod
+    def _softmax_hwc(pred, pads):
+        """(1, 3, Hp, Wp) logits -> (H, W, 3) softmax probabilities of the un-padded frame (device, current stream)"""
+        lib = _lib.load()
+        logits = pred.contiguous()
+        _, _, hp, wp = logits.shape
+        probs = torch.empty((hp - pads[0], wp - pads[1], 3), dtype=torch.float32, device=logits.device)
+        _lib.check(lib.mseg_softmax3_hwc(logits.data_ptr(), hp, wp, int(pads[0]), int(pads[1]), probs.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "softmax3_hwc")
+        return probs
 
     def infer_stack(self, img):
         """[T, H, W] stack -> [T, H, W] uint16 masks; per frame min/max + top/left padding exactly like
@@ -185,20 +191,19 @@ class InferWorker(QObject):
         self.net.eval()
         # Side streams for the post-processing.  Distance method: one (the watershed of frame i under the network of frame
         # i + 1).  Boundary method: its flood is ONE wavefront busy for ~45 ms per 2048^2 frame (the heap's
-        # marker phase is sequential by definition) — a latency, not a load: eight frames on eight streams flood side by
-        # side on eight compute units while the network goes on, each with its own workspace (postprocessing._workspace).
-        nside = self.BOUNDARY_STREAMS if boundary else 1
-        # (fresh streams per call, as before: HIP spreads new streams over its hardware queues, and a long-lived side stream
-        # that came to share a queue with the main or the copy stream cost the distance path 14 % — 257 vs 299 Mpx/s)
-        # Boundary method: HIGH-priority streams.  HIP multiplexes streams onto a few hardware queues per priority level, and
-        # kernels of streams that share a queue run one after the other: at the default priority a 45-ms flood sat in front of
-        # the network's kernels whenever its stream shared the main stream's queue (37 ms per frame, bf16 network, measured
-        # in a process of its own); high-priority streams have queues of their own (21 ms), and one wavefront takes nothing
-        # away from the network whatever its priority.
+        # marker phase is sequential by definition) — a latency, not a load.  The frames of a stack are collected in groups of
+        # BOUNDARY_BATCH and a group's floods go into ONE launch, one workgroup per frame (mseg_boundary_flood_batch: eight
+        # floods take the time of one); two side streams alternate between groups, each group on its own workspace slots,
+        # while the network goes on with the next frames.  HIGH-priority streams: HIP multiplexes streams onto a few hardware
+        # queues per priority level and kernels of streams that share a queue run one after the other — at the default
+        # priority a 45-ms flood sat in front of the network's kernels whenever its stream shared the main stream's queue.
+        batch = max(1, min(int(self.BOUNDARY_BATCH), 8)) if boundary else 1
+        nside = 2 if boundary else 1
         sides = [torch.cuda.Stream(device=self.device, priority=-1) if boundary else torch.cuda.Stream(device=self.device)
                  for _ in range(nside)]
-        in_flight = nside + 1
+        in_flight = 2 * batch if boundary else 2
         pending = []      # (frame index, pinned host mask, event on the side stream)
+        group, groups_done = [], [0]
 
         def finish(entry):
             f, host, ev = entry
@@ -207,28 +212,48 @@ class InferWorker(QObject):
                 results[f] = host.numpy().view(np.uint16)
             self.progress.emit(int(100 * (f + 1) / len(img)))
 
+        def flush_group():
+            """boundary method: softmax + post-processing of the collected frames on one side stream, their floods in one launch"""
+            if not group:
+                return
+            side = sides[groups_done[0] % nside]
+            slot0 = (groups_done[0] % nside) * 8
+            groups_done[0] += 1
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                outs = pp.boundary_postprocessing_batch_device([self._softmax_hwc(lg, pads) for _, lg, pads in group],
+                                                               first_slot=slot0)
+                for (frame, lg, _), (labels, _, _) in zip(group, outs):
+                    lg.record_stream(side)
+                    host = torch.empty(labels.shape, dtype=torch.int16, pin_memory=True)
+                    host.copy_(labels, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    pending.append((frame, host, done))
+            group.clear()
+
         def launch_postproc(frame, pred, pads):
             if self.prediction_hook is not None:
                 pred = self.prediction_hook(pred)
-            side = sides[frame % nside]
             if boundary:
-                logits = pred.contiguous()
-            else:
-                border, cell = pred
-                cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
-                border = border[0, 0, pads[0]:, pads[1]:].contiguous()
+                group.append((frame, pred.contiguous(), pads))
+                if len(group) >= batch:
+                    flush_group()
+                return
+            side = sides[0]
+            border, cell = pred
+            cell = cell[0, 0, pads[0]:, pads[1]:].contiguous()
+            border = border[0, 0, pads[0]:, pads[1]:].contiguous()
             ready = torch.cuda.Event()
             ready.record()
-            with torch.cuda.stream(side), pp.workspace_slot(frame % nside):
+            with torch.cuda.stream(side):
                 side.wait_event(ready)
-                if boundary:
-                    labels = self._postprocess(logits, pads)      # softmax + boundary post-processing on the side stream
-                    logits.record_stream(side)
-                else:
-                    labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1],
-                                                                     th_cell=self.ths[0], col_major_ids=True)
-                    border.record_stream(side)
-                    cell.record_stream(side)
+                labels, _, _ = pp.distance_postprocessing_device(border, cell, th_seed=self.ths[1],
+                                                                 th_cell=self.ths[0], col_major_ids=True)
+                border.record_stream(side)
+                cell.record_stream(side)
                 host = torch.empty(labels.shape, dtype=torch.int16, pin_memory=True)
                 host.copy_(labels, non_blocking=True)
                 done = torch.cuda.Event()
@@ -281,8 +306,9 @@ class InferWorker(QObject):
                     pending.append((frame, None, None))
                 else:
                     launch_postproc(frame, pred, pads)
-                while len(pending) > in_flight:  # distance: two frames in flight; boundary: one per side stream + 1
+                while len(pending) > in_flight:  # distance: two frames in flight; boundary: two groups
                     finish(pending.pop(0))
+            flush_group()
             while pending:
                 finish(pending.pop(0))
         return results

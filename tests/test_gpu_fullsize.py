@@ -293,10 +293,11 @@ def test_config4_stack_2048_through_infer_worker(tmp_path, dev):
 
 
 def test_boundary_stack_frames_in_flight_side_by_side(tmp_path, dev):
-    """infer_stack with a boundary-method model: the post-processing of up to InferWorker.BOUNDARY_STREAMS frames runs side by
-    side on as many streams (its flood is one wavefront per frame: a latency, not a load), each with its own workspace.
-    Eleven frames (more than streams: every stream is reused) whose logits a hook replaces by synthetic ones, frame by
-    frame different: the masks must equal the same post-processing done one frame after the other on one stream."""
+    """infer_stack with a boundary-method model: the frames are collected in groups of InferWorker.BOUNDARY_BATCH and a
+    group's floods go into one launch (one workgroup per frame: the flood is a latency, not a load), two side streams and
+    two sets of workspaces alternating between groups.  Twenty-one frames (two full groups on either stream and a short
+    one) whose logits a hook replaces by synthetic ones, frame by frame different: the masks must equal the same
+    post-processing done one frame after the other on one stream; the same with groups of 3 and of 1."""
     from microbeseg_amd.inference.infer import InferWorker
     from microbeseg_amd.utils import synth
     from microbeseg_amd.utils.unets import build_unet
@@ -306,13 +307,13 @@ def test_boundary_stack_frames_in_flight_side_by_side(tmp_path, dev):
     with open(tmp_path / "boundary_model_00.json", "w") as f:
         json.dump({"architecture": ["U", "conv", "relu", "bn", [8, 16]], "label_type": "boundary"}, f)
     worker = InferWorker(model=str(tmp_path / "boundary_model_00"), device="cuda:0")
-    assert worker.BOUNDARY_STREAMS == 8
-    T, H, W = 11, 512, 512
+    assert worker.BOUNDARY_BATCH == 8
+    T, H, W = 21, 512, 512
     rng = np.random.Generator(np.random.PCG64(77))
     stack = rng.integers(0, 60000, size=(T, H, W)).astype(np.uint16)
     logits = []
     for t in range(T):
-        cell, border = synth.synth_prediction_maps(rng, H, W, 40 + 9 * t, rmin=4.0, rmax=11.0)
+        cell, border = synth.synth_prediction_maps(rng, H, W, 40 + 5 * t, rmin=4.0, rmax=11.0)
         p1 = np.clip(cell * 2.0, 0, 1) * (1 - np.clip(border * 1.2, 0, 1))
         p2 = np.clip(border * 1.2, 0, 1) * (cell > 0.02)
         p0 = np.clip(1 - p1 - p2, 0.0, 1)
@@ -327,13 +328,15 @@ def test_boundary_stack_frames_in_flight_side_by_side(tmp_path, dev):
         return logits[calls[-1]]
 
     worker.prediction_hook = hook
-    got = worker.infer_stack(stack)
-    assert len(calls) == T and got.shape == (T, H, W) and got.dtype == np.uint16
-    n_inst = []
-    for t in range(T):
-        want = worker._postprocess(logits[t], [0, 0]).cpu().numpy().view(np.uint16)
-        assert np.array_equal(got[t], want), f"frame {t}: {int((got[t] != want).sum())} pixels differ"
-        n_inst.append(int(want.max()))
+    wants = [worker._postprocess(logits[t], [0, 0]).cpu().numpy().view(np.uint16) for t in range(T)]
+    n_inst = [int(w_.max()) for w_ in wants]
+    for nb in (8, 3, 1):
+        worker.BOUNDARY_BATCH = nb
+        del calls[:]
+        got = worker.infer_stack(stack)
+        assert len(calls) == T and got.shape == (T, H, W) and got.dtype == np.uint16
+        for t in range(T):
+            assert np.array_equal(got[t], wants[t]), f"groups of {nb}, frame {t}: {int((got[t] != wants[t]).sum())} pixels differ"
     print("instances per frame:", n_inst)
     assert min(n_inst) >= 20 and len(set(n_inst)) > 3
 

@@ -191,3 +191,38 @@ def test_component_flood_paths_agree(rows, tile_s, tile_l, pp):
                     assert int(status) & 1 == 0, "tie-free data must stay on the per-component flood"
     finally:
         assert lib.mseg_postproc_tuning(-1, -1, -1) == 0
+
+
+def test_boundary_batch_equals_single_frames():
+    """mseg_boundary_postprocess_pre / _flood_batch / _post (the floods of up to 8 frames in ONE launch, one workgroup per
+    frame) against mseg_boundary_postprocess frame by frame: labels, instance counts and status words identical, for
+    batches of 1, 3 and 8 DIFFERENT frames (touching cells, empty frame, one-cell frame), twice on the same workspaces."""
+    import torch
+    from microbeseg_amd.inference import postprocessing as pp
+    from microbeseg_amd.utils import synth
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.Generator(np.random.PCG64(321))
+    H, W = 300, 420
+    frames = []
+    for t in range(8):
+        ncell = [30, 0, 1, 80, 55, 12, 140, 7][t]
+        if ncell:
+            cell, border = synth.synth_prediction_maps(rng, H, W, ncell, rmin=4.0, rmax=12.0)
+        else:
+            cell, border = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+        p1 = np.clip(cell * 2.0, 0, 1) * (1 - np.clip(border * 1.2, 0, 1))
+        p2 = np.clip(border * 1.2, 0, 1) * (cell > 0.02)
+        p0 = np.clip(1 - p1 - p2, 0.0, 1)
+        probs = np.stack([p0, p1, p2], -1).astype(np.float32)
+        frames.append(torch.from_numpy(probs / np.maximum(probs.sum(-1, keepdims=True), 1e-9)).cuda())
+    single = [pp.boundary_postprocessing_device(f) for f in frames]
+    single = [(l.cpu().numpy().copy(), int(n), int(s)) for l, n, s in single]
+    assert max(n for _, n, _ in single) > 50
+    for B in (1, 3, 8, 8):
+        for start in range(0, 8, B):
+            got = pp.boundary_postprocessing_batch_device(frames[start:start + B], first_slot=2)
+            for k, (l, n, s) in enumerate(got):
+                want = single[start + k]
+                assert np.array_equal(l.cpu().numpy(), want[0]), (B, start + k)
+                assert (int(n), int(s)) == want[1:], (B, start + k)
