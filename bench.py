@@ -289,6 +289,17 @@ def inference_metric(args, net, dev):
         e1.record()
         torch.cuda.synchronize()
         t_bpp = e0.elapsed_time(e1) / 3
+        # the floods of 8 frames in one launch (one workgroup per frame): what a frame of a STACK costs
+        pp.boundary_postprocessing_batch_device([probs] * 8)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            outs8 = pp.boundary_postprocessing_batch_device([probs] * 8)
+        e1.record()
+        torch.cuda.synchronize()
+        t_bpp8 = e0.elapsed_time(e1) / 3 / 8
+        bpp8_equal = all(bool(torch.equal(o[0], bl)) for o in outs8)
     t0 = time.perf_counter()
     want = postproc_ref.distance_postprocessing(border[..., None], cell[..., None], 0.45, 0.10)
     t_cpu = time.perf_counter() - t0
@@ -418,6 +429,8 @@ def inference_metric(args, net, dev):
             "postproc_Mpx_s": round(S * S / t_pp / 1e3, 1), "instances": int(n_inst), "postproc_status": int(status),
             "labels_bit_exact_vs_oracle": exact,
             "boundary_stack": boundary_stack,
+            "boundary_postproc_batch8": {"value": round(S * S / t_bpp8 / 1e3, 1), "unit": "Mpx/s", "ms_per_frame": round(t_bpp8, 2),
+                                         "labels_equal_single_frame": bpp8_equal},
             "boundary_postproc": {"value": round(S * S / t_bpp / 1e3, 1), "unit": "Mpx/s", "ms": round(t_bpp, 2),
                                   "instances": int(bn), "status": int(bs), "labels_bit_exact_vs_oracle": exact_b},
             "cpu_postproc": {"value": round(S * S / t_cpu / 1e6, 2), "unit": "Mpx/s", "cores": 1, "kind": "port",
