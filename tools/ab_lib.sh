@@ -7,7 +7,7 @@ sets=$1; shift
 for i in 1 2 3 4 5; do
 for s in $sets; do
 if [[ "$s" == *=* ]]; then pre="$s"; else pre="MSEG_HIP_LIB=$PWD/microbeseg_amd/$s"; fi
-env $pre python bench.py --steps 30 --warmup 5 --no-inference --no-cpu-baseline --no-kernel-timing --no-bf16-block "$@" 2>&1 | python -c "
+env $pre python bench.py --train-only --steps 30 --warmup 5 --no-inference --no-cpu-baseline --no-kernel-timing --no-bf16-block "$@" 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

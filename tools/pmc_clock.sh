@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_clock_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/g1 -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block "$@" > $out/g1.log 2>&1 || echo "pass failed"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/g1 -o t -- python3 $GRAFT_REPO_ROOT/bench.py --train-only --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block "$@" > $out/g1.log 2>&1 || echo "pass failed"
 cd $out
 python3 - "$tag" <<'PY'
 import csv, glob, collections, json, sys

@@ -12,7 +12,7 @@ i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum" "SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference "$@" > $out/g$i.log 2>&1 || echo "group $i failed: $grp"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/g$i -o t -- python3 $GRAFT_REPO_ROOT/bench.py --train-only --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference "$@" > $out/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 cd $out
 python3 - "$tag" <<'PY'

@@ -10,7 +10,7 @@ out=$PWD/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block "$@" > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o t -- python3 $GRAFT_REPO_ROOT/bench.py --train-only --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block "$@" > $out/$c.log 2>&1
 done
 cd $out
 python3 - "$tag" "$GRAFT_REPO_ROOT" "$@" <<'PY'

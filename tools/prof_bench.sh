@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --train-only "$@" --no-cpu-baseline --no-kernel-timing --no-inference --no-bf16-block > $out/bench.log 2>&1
 cd $out
 f=$(find . -name '*kernel_stats.csv' | head -1)
 echo "stats file: $f"

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_infer_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-bf16-block --infer-frames 8 "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --inference-only --infer-frames 8 "$@" > $out/bench.log 2>&1
 cd $out
 python3 - <<'PY'
 import csv
