@@ -198,6 +198,9 @@ class InferWorker(QObject):
         # queues per priority level and kernels of streams that share a queue run one after the other — at the default
         # priority a 45-ms flood sat in front of the network's kernels whenever its stream shared the main stream's queue.
         batch = max(1, min(int(self.BOUNDARY_BATCH), 8)) if boundary else 1
+        if boundary:      # two groups' workspaces (0.32 GiB per 2048^2 frame, 5.2 GiB per 8192^2 frame) stay below ~16 GiB
+            per_frame = max(1, _lib.load().mseg_postproc_workspace_bytes(int(img.shape[1]), int(img.shape[2])))
+            batch = max(1, min(batch, (8 << 30) // per_frame))
         nside = 2 if boundary else 1
         sides = [torch.cuda.Stream(device=self.device, priority=-1) if boundary else torch.cuda.Stream(device=self.device)
                  for _ in range(nside)]
